@@ -1,0 +1,105 @@
+"""ctypes binding of libd4gs.so (the C ABI declared in include/d4gs.h).
+
+The product path has NO fallback: if the HIP library is missing this module raises at first use, and every
+entry point raises RuntimeError on a non-zero return code with `d4gs_last_error()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libd4gs.so")
+
+F = C.c_void_p  # device pointers travel as void*
+
+
+class Dims(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("G", C.c_int32), ("K", C.c_int32), ("T", C.c_int32), ("S", C.c_int32), ("D", C.c_int32),
+        ("width", C.c_int32), ("height", C.c_int32), ("depth_mode", C.c_int32), ("flags", C.c_int32),
+        ("n_sigmoid", C.c_int32),
+        ("near_plane", C.c_float), ("far_plane", C.c_float), ("eps2d", C.c_float), ("radius_clip", C.c_float),
+    ]
+
+
+class ProjIn(C.Structure):
+    _fields_ = [(n, F) for n in ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls",
+                                 "times", "RTs", "viewmat", "Kmat")]
+
+
+class ProjOut(C.Structure):
+    _fields_ = [(n, F) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tiles_touched",
+                                 "isect_offsets", "tile_counts", "tile_offsets", "n_isect", "scan_ws")]
+
+
+class Isect(C.Structure):
+    _fields_ = [("n_isect", C.c_int64)] + [(n, F) for n in ("keys", "gid_of_emit", "sorted_gid", "sorted_emit")]
+
+
+class Raster(C.Structure):
+    _fields_ = [(n, F) for n in ("background", "render_colors", "render_alphas", "last_ids")]
+
+
+class RasterGrads(C.Structure):
+    _fields_ = [(n, F) for n in ("v_render_colors", "v_render_alphas", "isect_grad", "v_means2d", "v_conics",
+                                 "v_depths", "v_opac_act", "v_ctab")]
+
+
+class LeafGrads(C.Structure):
+    _fields_ = [(n, F) for n in ("v_means", "v_quats", "v_scales", "v_opacities", "v_colors", "v_motion_coefs",
+                                 "v_rots", "v_transls", "v_times", "v_RTs", "v_viewmat", "partials")]
+
+
+RAW_PARAMS, RAW_COLORS = 1, 2
+DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
+TILE = 16
+GEOM_STRIDE = 8
+
+EXPORTS = (
+    "d4gs_version", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
+    "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
+)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `python -m deblur4dgs_amd.build` (hipcc, --offload-arch=gfx950)."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(L, name)  # AttributeError if the symbol is missing
+        L.d4gs_last_error.restype = C.c_char_p
+        L.d4gs_scan_ws_elems.restype = C.c_size_t
+        L.d4gs_scan_ws_elems.argtypes = [C.c_int64]
+        L.d4gs_bwd_partials_elems.restype = C.c_size_t
+        L.d4gs_bwd_partials_elems.argtypes = [C.POINTER(Dims)]
+        if L.d4gs_version() != 100:
+            raise RuntimeError(f"libd4gs.so version {L.d4gs_version()} != 100 (stale build?)")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().d4gs_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (or NULL for None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "d4gs expects contiguous tensors"
+    return t.data_ptr()
+
+
+def fill(struct, **tensors):
+    for k, v in tensors.items():
+        setattr(struct, k, ptr(v))
+    return struct

@@ -1,0 +1,148 @@
+// binning.hip -- tile binning pass 2 (emit) and the per-tile depth sort.
+//
+// Replaces gsplat isect_tiles (second pass) + cub::DeviceRadixSort over n_isect 64-bit keys +
+// isect_offset_encode (reference call site flow3d/scene_model.py:360-373).
+//
+// MI355X design: the global sort only has to group by tile, which the counting pass (atomic histogram in
+// k_project_fwd + one scan) already did; what remains is a SHORT depth sort per tile, done by one workgroup
+// per (sub-sample, tile) entirely in LDS (160 KB/CU) with a bitonic network whose comparators all point the
+// same way (so lists need no +inf padding).  Key = float-bits(depth) << 32 | emission index; the emission
+// index grows with the Gaussian id inside one sub-sample, which reproduces the stable-radix tie order of the
+// reference path exactly.
+#include "common.h"
+
+namespace {
+
+struct EmitArgs {
+  D4gsDims d;
+  const float *geom;
+  const int32_t *radii;
+  const int32_t *tiles_touched;
+  const int32_t *isect_offsets;
+  int32_t *tile_cursor;  // tile_counts, counted down to 0
+  const int32_t *tile_offsets;
+  uint64_t *keys;
+  int32_t *gid_of_emit;
+  int tw, th;
+};
+
+__global__ void __launch_bounds__(256) k_emit(const EmitArgs a) {
+  const int64_t n_inst = (int64_t)a.d.S * a.d.N;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_inst) return;
+  const int cnt = a.tiles_touched[i];
+  if (cnt == 0) return;
+  const int s = (int)(i / a.d.N), g = (int)(i - (int64_t)s * a.d.N);
+  const float4 g0 = *reinterpret_cast<const float4 *>(a.geom + i * D4GS_GEOM_STRIDE);
+  int x0, y0, x1, y1;
+  tile_rect(g0.x, g0.y, a.radii[i], a.tw, a.th, x0, y0, x1, y1);
+  const uint64_t hi = (uint64_t)__float_as_uint(g0.w) << 32;
+  uint32_t e = (uint32_t)a.isect_offsets[i];
+  const int tbase = s * a.tw * a.th;
+  for (int ty = y0; ty < y1; ty++)
+    for (int tx = x0; tx < x1; tx++) {
+      const int t = tbase + ty * a.tw + tx;
+      const int slot = a.tile_offsets[t] + atomicSub(a.tile_cursor + t, 1) - 1;
+      a.keys[slot] = hi | e;
+      a.gid_of_emit[e] = g;
+      e++;
+    }
+}
+
+// all-ascending bitonic network on `n` keys (any n): step (k, j) compares i with its partner l > i.
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr key, int n) {
+  int P = 1;
+  while (P < n) P <<= 1;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+        const int blk = t / j, off = t - blk * j;
+        const int i = blk * 2 * j + off;
+        const int l = (j == (k >> 1)) ? (blk * 2 * j + (2 * j - 1 - off)) : (i + j);
+        if (l < n) {
+          uint64_t a = key[i], b = key[l];
+          if (a > b) {
+            key[i] = b;
+            key[l] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct SortArgs {
+  const int32_t *tile_offsets;
+  uint64_t *keys;
+  const int32_t *gid_of_emit;
+  int32_t *sorted_gid;
+  int32_t *sorted_emit;
+  int cap;
+};
+
+__global__ void __launch_bounds__(256) k_tile_sort(const SortArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+  const int t = blockIdx.x;
+  const int base = a.tile_offsets[t];
+  const int n = a.tile_offsets[t + 1] - base;
+  if (n <= 0) return;
+  uint64_t *gk = a.keys + base;
+  if (n <= a.cap) {
+    for (int p = threadIdx.x; p < n; p += blockDim.x) skeys[p] = gk[p];
+    __syncthreads();
+    bitonic_sort(skeys, n);
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+      const uint32_t e = (uint32_t)skeys[p];
+      a.sorted_emit[base + p] = (int32_t)e;
+      a.sorted_gid[base + p] = a.gid_of_emit[e];
+    }
+  } else {  // list longer than the LDS budget: same network on global memory (rare; correctness path)
+    bitonic_sort(gk, n);
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+      const uint32_t e = (uint32_t)gk[p];
+      a.sorted_emit[base + p] = (int32_t)e;
+      a.sorted_gid[base + p] = a.gid_of_emit[e];
+    }
+  }
+}
+
+}  // namespace
+
+int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream) {
+  if (isect->n_isect <= 0) return D4GS_OK;
+  if (isect->n_isect >= (int64_t)0x7fffffff) {
+    d4gs_set_error("n_isect=%lld exceeds int32 indexing", (long long)isect->n_isect);
+    return D4GS_ECAPACITY;
+  }
+  EmitArgs e;
+  e.d = *dims;
+  e.geom = proj->geom;
+  e.radii = proj->radii;
+  e.tiles_touched = proj->tiles_touched;
+  e.isect_offsets = proj->isect_offsets;
+  e.tile_cursor = proj->tile_counts;
+  e.tile_offsets = proj->tile_offsets;
+  e.keys = isect->keys;
+  e.gid_of_emit = isect->gid_of_emit;
+  e.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
+  e.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
+  const int64_t n_inst = (int64_t)dims->S * dims->N;
+  hipLaunchKernelGGL(k_emit, dim3((unsigned)((n_inst + 255) / 256)), dim3(256), 0, stream, e);
+  int rc = d4gs_check_launch("k_emit");
+  if (rc) return rc;
+  const int n_tiles = dims->S * e.tw * e.th;
+  // LDS budget: 4x the mean list length, clamped to [2048, 16384] keys (16..128 KB)
+  int64_t avg = isect->n_isect / n_tiles + 1;
+  int cap = 2048;
+  while (cap < 4 * avg && cap < 16384) cap <<= 1;
+  SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit, cap};
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_tile_sort, dim3(n_tiles), dim3(256), (size_t)cap * 8, stream, s);
+  return d4gs_check_launch("k_tile_sort");
+}

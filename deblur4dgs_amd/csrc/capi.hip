@@ -1,0 +1,118 @@
+// capi.hip -- the extern "C" surface of libd4gs.so (declared in include/d4gs.h) and error plumbing.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+int d4gs_project_fwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, hipStream_t);
+int d4gs_bin_sort_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, hipStream_t);
+int d4gs_raster_fwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, const D4gsRaster *, hipStream_t);
+int d4gs_raster_bwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, const D4gsRaster *,
+                         const D4gsRasterGrads *, hipStream_t);
+int d4gs_project_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, const float *, const float *,
+                          const float *, const float *, const float *, const D4gsLeafGrads *, hipStream_t);
+int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *,
+                        hipStream_t);
+int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
+                        const float *, float *, float *, hipStream_t);
+
+static thread_local char g_err[512] = "";
+
+void d4gs_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int d4gs_check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    d4gs_set_error("%s: %s", what, hipGetErrorString(e));
+    return D4GS_ELAUNCH;
+  }
+  return D4GS_OK;
+}
+
+static int check_dims(const D4gsDims *d) {
+  if (!d) {
+    d4gs_set_error("dims is NULL");
+    return D4GS_EINVAL;
+  }
+  if (d->N < 0 || d->S <= 0 || d->width <= 0 || d->height <= 0 || d->D <= 0) {
+    d4gs_set_error("bad dims N=%d S=%d W=%d H=%d D=%d", d->N, d->S, d->width, d->height, d->D);
+    return D4GS_EINVAL;
+  }
+  if (d->G < 0 || d->G > d->N || (d->G > 0 && (d->K <= 0 || d->K > D4GS_MAX_K || d->T <= 0))) {
+    d4gs_set_error("bad motion dims G=%d K=%d (max %d) T=%d", d->G, d->K, D4GS_MAX_K, d->T);
+    return D4GS_EINVAL;
+  }
+  return D4GS_OK;
+}
+
+extern "C" {
+
+int d4gs_version(void) { return D4GS_VERSION; }
+const char *d4gs_last_error(void) { return g_err; }
+
+int d4gs_project_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, void *stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  if (!in || !out || !in->means || !in->quats || !in->scales || !in->opacities || !in->colors || !in->viewmat ||
+      !in->Kmat) {
+    d4gs_set_error("d4gs_project_fwd: NULL required input");
+    return D4GS_EINVAL;
+  }
+  if (dims->G > 0 && (!in->motion_coefs || !in->rots || !in->transls || !in->times)) {
+    d4gs_set_error("d4gs_project_fwd: G>0 needs motion_coefs/rots/transls/times");
+    return D4GS_EINVAL;
+  }
+  if (dims->N == 0) {
+    d4gs_set_error("d4gs_project_fwd: N == 0");
+    return D4GS_EINVAL;
+  }
+  return d4gs_project_fwd_impl(dims, in, out, (hipStream_t)stream);
+}
+
+int d4gs_bin_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, void *stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  return d4gs_bin_sort_impl(dims, proj, isect, (hipStream_t)stream);
+}
+
+int d4gs_raster_fwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
+                    void *stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  return d4gs_raster_fwd_impl(dims, proj, isect, r, (hipStream_t)stream);
+}
+
+int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
+                    const D4gsRasterGrads *g, void *stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  return d4gs_raster_bwd_impl(dims, proj, isect, r, g, (hipStream_t)stream);
+}
+
+int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *proj, const float *v_means2d,
+                     const float *v_conics, const float *v_depths, const float *v_opac_act, const float *v_ctab,
+                     const D4gsLeafGrads *grads, void *stream) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  return d4gs_project_bwd_impl(dims, in, proj, v_means2d, v_conics, v_depths, v_opac_act, v_ctab, grads,
+                               (hipStream_t)stream);
+}
+
+int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy, const float *renders,
+                   const float *alphas, float *out, float *acc, void *stream) {
+  return d4gs_blend_fwd_impl(S, n_pixels, C, policy, renders, alphas, out, acc, (hipStream_t)stream);
+}
+
+int d4gs_blend_bwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy, const float *renders,
+                   const float *out, const float *v_out, const float *v_acc, float *v_renders, float *v_alphas,
+                   void *stream) {
+  return d4gs_blend_bwd_impl(S, n_pixels, C, policy, renders, out, v_out, v_acc, v_renders, v_alphas,
+                             (hipStream_t)stream);
+}
+
+}  // extern "C"

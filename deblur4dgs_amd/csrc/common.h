@@ -1,0 +1,199 @@
+// common.h -- device helpers shared by the d4gs HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/d4gs.h"
+
+#define D4GS_WAVE 64
+#define D4GS_MAX_K 32         // motion bases held in LDS per block
+#define D4GS_PROJ_BLOCK 256
+
+// host-side error plumbing (capi.cpp)
+void d4gs_set_error(const char *fmt, ...);
+int d4gs_check_launch(const char *what);
+
+struct float9 {
+  float m[9];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// 3x3 row-major helpers -----------------------------------------------------------------------
+__device__ __forceinline__ void mat3_mul(const float *A, const float *B, float *C) {  // C = A B
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_mul_bt(const float *A, const float *B, float *C) {  // C = A B^T
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      C[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+}
+__device__ __forceinline__ void mat3_mul_at(const float *A, const float *B, float *C) {  // C = A^T B
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+// unit quaternion (w,x,y,z) -> rotation matrix
+__device__ __forceinline__ void quat_to_rotmat(float w, float x, float y, float z, float *R) {
+  R[0] = 1.f - 2.f * (y * y + z * z);
+  R[1] = 2.f * (x * y - w * z);
+  R[2] = 2.f * (x * z + w * y);
+  R[3] = 2.f * (x * y + w * z);
+  R[4] = 1.f - 2.f * (x * x + z * z);
+  R[5] = 2.f * (y * z - w * x);
+  R[6] = 2.f * (x * z - w * y);
+  R[7] = 2.f * (y * z + w * x);
+  R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Gram-Schmidt of a 6-D rotation (transforms.py:41-53): columns x, y, z.  Keeps the pieces the adjoint needs.
+struct GS6 {
+  float x[3], y[3], z[3];
+  float inv_na, inv_nb;  // 1/max(|a|,eps), 1/max(|b'|,eps)
+  float d;               // b . x
+};
+__device__ __forceinline__ void gram_schmidt(const float *r6, GS6 &o) {
+  float na = sqrtf(r6[0] * r6[0] + r6[1] * r6[1] + r6[2] * r6[2]);
+  o.inv_na = 1.f / fmaxf(na, 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 3; i++) o.x[i] = r6[i] * o.inv_na;
+  o.d = r6[3] * o.x[0] + r6[4] * o.x[1] + r6[5] * o.x[2];
+  float bp[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) bp[i] = r6[3 + i] - o.d * o.x[i];
+  float nb = sqrtf(bp[0] * bp[0] + bp[1] * bp[1] + bp[2] * bp[2]);
+  o.inv_nb = 1.f / fmaxf(nb, 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 3; i++) o.y[i] = bp[i] * o.inv_nb;
+  o.z[0] = o.x[1] * o.y[2] - o.x[2] * o.y[1];
+  o.z[1] = o.x[2] * o.y[0] - o.x[0] * o.y[2];
+  o.z[2] = o.x[0] * o.y[1] - o.x[1] * o.y[0];
+}
+
+// gsplat isect_tiles rectangle: tile_min inclusive, tile_max exclusive (float32 arithmetic as upstream)
+__device__ __forceinline__ void tile_rect(float mx, float my, int radius, int tw, int th, int &x0, int &y0, int &x1,
+                                          int &y1) {
+  const float inv = 1.0f / D4GS_TILE;
+  float tx = mx * inv, ty = my * inv, tr = (float)radius * inv;
+  x0 = (int)fminf(fmaxf(floorf(tx - tr), 0.f), (float)tw);
+  y0 = (int)fminf(fmaxf(floorf(ty - tr), 0.f), (float)th);
+  x1 = (int)fminf(fmaxf(ceilf(tx + tr), 0.f), (float)tw);
+  y1 = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)th);
+}
+
+// camera constants, uniform across the grid (passed by value as a kernel argument -> SGPRs)
+struct Cam {
+  float R[9];  // world->camera rotation
+  float t[3];
+  float fx, fy, cx, cy;
+  float limx, limy;  // 1.3 * tan(fov/2)
+};
+
+// viewmat [4,4] / K [3,3] live in device memory (viewmat may carry a gradient); addresses are grid-uniform so
+// these become scalar loads.
+__device__ __forceinline__ Cam load_cam(const float *V, const float *Km, int width, int height) {
+  Cam c;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) c.R[i * 3 + j] = V[i * 4 + j];
+    c.t[i] = V[i * 4 + 3];
+  }
+  c.fx = Km[0], c.fy = Km[4], c.cx = Km[2], c.cy = Km[5];
+  c.limx = 1.3f * (0.5f * (float)width / c.fx);
+  c.limy = 1.3f * (0.5f * (float)height / c.fy);
+  return c;
+}
+
+// Perspective projection of one instance (gsplat fully_fused_projection).
+// Rm = instance rotation (world), sc = scales, mw = world mean AFTER the camera delta.
+struct ProjOut {
+  float pc[3];      // camera-space mean
+  float M[9];       // Rcw * Rm * diag(sc)   (camera-space "sqrt" of the covariance)
+  float covc[6];    // camera-space covariance (xx,xy,xz,yy,yz,zz)
+  float J02, J12;   // -fx*tx/z^2, -fy*ty/z^2
+  float rz;
+  float a, b, c;    // blurred 2-D covariance
+  float det;
+  float mx, my;
+  int radius;       // 0 = culled
+  bool in_x, in_y;  // inside the 1.3*tan(fov) clamp
+};
+
+__device__ __forceinline__ void project_instance(const Cam &cam, const float *mw, const float *Rm, const float *sc,
+                                                 const D4gsDims &d, ProjOut &o) {
+  o.radius = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) o.pc[i] = cam.R[i * 3] * mw[0] + cam.R[i * 3 + 1] * mw[1] + cam.R[i * 3 + 2] * mw[2] + cam.t[i];
+  float z = o.pc[2];
+  if (!(z >= d.near_plane && z <= d.far_plane)) return;
+  float W_[9];
+  mat3_mul(cam.R, Rm, W_);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) o.M[i * 3 + j] = W_[i * 3 + j] * sc[j];
+  const float *M = o.M;
+  o.covc[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+  o.covc[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+  o.covc[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+  o.covc[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+  o.covc[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+  o.covc[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+  float rz = 1.f / z, rz2 = rz * rz;
+  o.rz = rz;
+  float xr = o.pc[0] * rz, yr = o.pc[1] * rz;
+  o.in_x = (xr <= cam.limx) && (xr >= -cam.limx);
+  o.in_y = (yr <= cam.limy) && (yr >= -cam.limy);
+  float tx = z * fminf(cam.limx, fmaxf(-cam.limx, xr));
+  float ty = z * fminf(cam.limy, fmaxf(-cam.limy, yr));
+  float J00 = cam.fx * rz, J11 = cam.fy * rz;
+  o.J02 = -cam.fx * tx * rz2;
+  o.J12 = -cam.fy * ty * rz2;
+  // cov2d = J covc J^T,  J = [[J00,0,J02],[0,J11,J12]]
+  const float cxx = o.covc[0], cxy = o.covc[1], cxz = o.covc[2], cyy = o.covc[3], cyz = o.covc[4], czz = o.covc[5];
+  float c00 = J00 * J00 * cxx + 2.f * J00 * o.J02 * cxz + o.J02 * o.J02 * czz;
+  float c01 = J00 * J11 * cxy + J00 * o.J12 * cxz + o.J02 * J11 * cyz + o.J02 * o.J12 * czz;
+  float c11 = J11 * J11 * cyy + 2.f * J11 * o.J12 * cyz + o.J12 * o.J12 * czz;
+  o.a = c00 + d.eps2d;
+  o.b = c01;
+  o.c = c11 + d.eps2d;
+  o.det = o.a * o.c - o.b * o.b;
+  if (!(o.det > 0.f)) return;
+  float mid = 0.5f * (o.a + o.c);
+  float v1 = mid + sqrtf(fmaxf(0.01f, mid * mid - o.det));
+  float radius = ceilf(3.f * sqrtf(v1));
+  if (radius <= d.radius_clip) return;
+  o.mx = cam.fx * o.pc[0] * rz + cam.cx;
+  o.my = cam.fy * o.pc[1] * rz + cam.cy;
+  if (o.mx + radius <= 0.f || o.mx - radius >= (float)d.width || o.my + radius <= 0.f ||
+      o.my - radius >= (float)d.height)
+    return;
+  o.radius = (int)radius;
+}
+
+// wave64 sum: 6 DPP adds, total lands in lane 63 (GFX9 row_bcast forms).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float x) {
+  int v = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, true);
+  return x + __int_as_float(v);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float x) {
+  x = dpp_add<0xB1>(x);        // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);        // quad_perm [2,3,0,1]
+  x = dpp_add<0x141>(x);       // row_half_mirror
+  x = dpp_add<0x140>(x);       // row_mirror  -> every lane holds its 16-lane row sum
+  x = dpp_add<0x142, 0xA>(x);  // row_bcast:15 into rows 1,3
+  x = dpp_add<0x143, 0xC>(x);  // row_bcast:31 into rows 2,3
+  return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(x)), 63));
+}

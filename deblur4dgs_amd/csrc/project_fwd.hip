@@ -1,0 +1,282 @@
+// project_fwd.hip -- fused activations + motion-basis deformation + camera delta + perspective projection
+// + tile counting for ALL exposure sub-samples of one blurry frame, and the two exclusive scans that
+// lay out the intersection lists.
+//
+// Replaces, per render call (reference flow3d/scene_model.py:323-373, S iterations of ~60 torch launches):
+//   params.py:39-43 (activations), params.py:142-180 (compute_transforms), transforms.py:41-53,
+//   scene_model.py:89-102 (pose compose; done on rotation MATRICES),
+//   scene_model.py:352-353 (camera delta), gsplat fully_fused_projection_fwd, gsplat isect_tiles pass 1.
+//
+// Work decomposition: one lane per Gaussian g, looping over the S sub-samples, so leaf parameters are read
+// from HBM once and reused S times (coalesced SoA-by-tensor loads: consecutive lanes read consecutive rows).
+// Per-block LDS: the S*K*9 time-blended bases (broadcast reads) and the block's softmaxed coefficients.
+#include "common.h"
+
+namespace {
+
+struct FwdArgs {
+  D4gsDims d;
+  D4gsProjIn in;
+  D4gsProjOut out;
+  int tw, th;
+};
+
+// time-blended bases: Bs[s][k][0:3] = transl, [3:9] = 6-D rotation   (params.py:152-177; w uses the clamped floor)
+__device__ __forceinline__ void preblend_bases(const FwdArgs &a, float *Bs) {
+  const int K = a.d.K, T = a.d.T;
+  for (int idx = threadIdx.x; idx < a.d.S * K * 9; idx += blockDim.x) {
+    int s = idx / (K * 9), r = idx - s * K * 9, k = r / 9, j = r - k * 9;
+    float t = a.in.times[s];
+    float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));
+    float cf = fminf(fmaxf(ceilf(t), 0.f), (float)(T - 1));
+    float w = t - ff;
+    int f = (int)ff, c = (int)cf;
+    float vf, vc;
+    if (j < 3) {
+      vf = a.in.transls[(k * T + f) * 3 + j];
+      vc = a.in.transls[(k * T + c) * 3 + j];
+    } else {
+      vf = a.in.rots[(k * T + f) * 6 + j - 3];
+      vc = a.in.rots[(k * T + c) * 6 + j - 3];
+    }
+    Bs[idx] = (1.f - w) * vf + w * vc;
+  }
+}
+
+__global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const D4gsDims &d = a.d;
+  const int N = d.N, G = d.G, K = d.K, S = d.S;
+  float *Bs = smem;                                  // [S][K][9]
+  float *cf = smem + ((S * K * 9 + 3) & ~3);         // [K][BLOCK]
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x * D4GS_PROJ_BLOCK + tid;
+  const Cam cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
+  const bool dyn_block = (blockIdx.x * D4GS_PROJ_BLOCK) < G;
+  if (dyn_block) preblend_bases(a, Bs);
+
+  const bool active = g < N;
+  const bool raw = d.flags & D4GS_RAW_PARAMS;
+  float mu[3] = {0, 0, 0}, Rq[9], sc[3] = {1, 1, 1}, opac = 0.f;
+  if (active) {
+    mu[0] = a.in.means[g * 3];
+    mu[1] = a.in.means[g * 3 + 1];
+    mu[2] = a.in.means[g * 3 + 2];
+    const float4 q = *reinterpret_cast<const float4 *>(a.in.quats + (size_t)g * 4);
+    float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    quat_to_rotmat(q.x * inv, q.y * inv, q.z * inv, q.w * inv, Rq);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float v = a.in.scales[g * 3 + j];
+      sc[j] = raw ? expf(v) : v;
+    }
+    opac = a.in.opacities[g];
+    if (raw) opac = 1.f / (1.f + expf(-opac));
+    a.out.opac_act[g] = opac;
+    const int D = d.D, DP = (D + 3) & ~3;
+    for (int ch = 0; ch < DP; ch++) {
+      float v = 0.f;
+      if (ch < D) {
+        v = a.in.colors[(size_t)g * D + ch];
+        if ((d.flags & D4GS_RAW_COLORS) && ch < d.n_sigmoid) v = 1.f / (1.f + expf(-v));
+      }
+      a.out.ctab[(size_t)g * DP + ch] = v;
+    }
+    if (g < G) {  // softmax(motion_coefs)  params.py:43
+      const float *mc = a.in.motion_coefs + (size_t)g * K;
+      float m = -INFINITY;
+      for (int k = 0; k < K; k++) m = fmaxf(m, mc[k]);
+      float sum = 0.f;
+      for (int k = 0; k < K; k++) {
+        float e = expf(mc[k] - m);
+        cf[k * D4GS_PROJ_BLOCK + tid] = e;
+        sum += e;
+      }
+      float is = 1.f / sum;
+      for (int k = 0; k < K; k++) cf[k * D4GS_PROJ_BLOCK + tid] *= is;
+    }
+  }
+  if (dyn_block) __syncthreads();
+
+  for (int s = 0; s < S; s++) {
+    if (!active) continue;
+    float mw[3], Rm[9];
+    if (g < G) {
+      float v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const float *B = Bs + s * K * 9;
+      for (int k = 0; k < K; k++) {
+        float c = cf[k * D4GS_PROJ_BLOCK + tid];
+#pragma unroll
+        for (int j = 0; j < 9; j++) v9[j] += c * B[k * 9 + j];
+      }
+      GS6 gs;
+      gram_schmidt(v9 + 3, gs);
+      float Rd[9] = {gs.x[0], gs.y[0], gs.z[0], gs.x[1], gs.y[1], gs.z[1], gs.x[2], gs.y[2], gs.z[2]};
+#pragma unroll
+      for (int i = 0; i < 3; i++) mw[i] = Rd[i * 3] * mu[0] + Rd[i * 3 + 1] * mu[1] + Rd[i * 3 + 2] * mu[2] + v9[i];
+      mat3_mul(Rd, Rq, Rm);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) mw[i] = mu[i];
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rm[i] = Rq[i];
+    }
+    if (a.in.RTs) {  // camera delta: means only (scene_model.py:352-353)
+      const float *RT = a.in.RTs + s * 12;
+      float t0 = RT[0] * mw[0] + RT[1] * mw[1] + RT[2] * mw[2] + RT[3];
+      float t1 = RT[4] * mw[0] + RT[5] * mw[1] + RT[6] * mw[2] + RT[7];
+      float t2 = RT[8] * mw[0] + RT[9] * mw[1] + RT[10] * mw[2] + RT[11];
+      mw[0] = t0, mw[1] = t1, mw[2] = t2;
+    }
+    ProjOut p;
+    project_instance(cam, mw, Rm, sc, d, p);
+    const size_t i = (size_t)s * N + g;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    float m2x = 0.f, m2y = 0.f, dep = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    int cnt = 0;
+    if (p.radius > 0) {
+      float idet = 1.f / p.det;
+      ca = p.c * idet, cb = -p.b * idet, cc = p.a * idet;
+      m2x = p.mx, m2y = p.my, dep = p.pc[2];
+      g0 = make_float4(m2x, m2y, opac, dep);
+      g1 = make_float4(ca, cb, cc, 0.f);
+      int x0, y0, x1, y1;
+      tile_rect(m2x, m2y, p.radius, a.tw, a.th, x0, y0, x1, y1);
+      cnt = (x1 - x0) * (y1 - y0);
+      int *tc = a.out.tile_counts + (size_t)s * a.tw * a.th;
+      for (int ty = y0; ty < y1; ty++)
+        for (int tx = x0; tx < x1; tx++) atomicAdd(tc + ty * a.tw + tx, 1);
+    }
+    a.out.radii[i] = p.radius;
+    *reinterpret_cast<float2 *>(a.out.means2d + i * 2) = make_float2(m2x, m2y);
+    a.out.depths[i] = dep;
+    a.out.conics[i * 3] = ca;
+    a.out.conics[i * 3 + 1] = cb;
+    a.out.conics[i * 3 + 2] = cc;
+    a.out.tiles_touched[i] = cnt;
+    float4 *gp = reinterpret_cast<float4 *>(a.out.geom + i * D4GS_GEOM_STRIDE);
+    gp[0] = g0;
+    gp[1] = g1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// exclusive scan (int32) : block sums -> one block scans the sums -> apply.  2048 items per block.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int *total, int *lds /* [SCAN_THREADS/64 + 1] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+    int x = lds[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(const int *in, int64_t n, int *sums) {
+  __shared__ int lds[8];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++)
+    if (base + j < n) s += in[base + j];
+  int tot;
+  block_exclusive_scan(s, &tot, lds);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of `n` ints in place (looping with a carry); optionally writes the total to
+// out[n] (int32) and to total64.
+__global__ void __launch_bounds__(1024) k_scan_single(const int *in, int *out, int64_t n, int write_last,
+                                                       int64_t *total64) {
+  __shared__ int lds[20];
+  int64_t carry = 0;
+  for (int64_t base = 0; base < n; base += blockDim.x) {
+    int64_t i = base + threadIdx.x;
+    int v = i < n ? in[i] : 0;
+    int tot;
+    int ex = block_exclusive_scan(v, &tot, lds);
+    if (i < n) out[i] = (int)(carry + ex);
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    if (write_last) out[n] = (int)carry;
+    if (total64) *total64 = carry;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const int *in, const int *sums_ex, int64_t n, int *out) {
+  __shared__ int lds[8];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    v[j] = (base + j < n) ? in[base + j] : 0;
+    s += v[j];
+  }
+  int tot;
+  int ex = block_exclusive_scan(s, &tot, lds) + sums_ex[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
+}  // namespace
+
+extern "C" size_t d4gs_scan_ws_elems(int64_t n_instances) {
+  return (size_t)((n_instances + SCAN_TILE - 1) / SCAN_TILE) + 16;
+}
+
+int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, hipStream_t stream) {
+  FwdArgs a;
+  a.d = *dims;
+  a.in = *in;
+  a.out = *out;
+  a.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
+  a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
+  const int64_t n_inst = (int64_t)dims->S * dims->N;
+  const int64_t n_tiles = (int64_t)dims->S * a.tw * a.th;
+  hipError_t e = hipMemsetAsync(out->tile_counts, 0, sizeof(int32_t) * n_tiles, stream);
+  if (e != hipSuccess) {
+    d4gs_set_error("hipMemsetAsync(tile_counts): %s", hipGetErrorString(e));
+    return D4GS_ELAUNCH;
+  }
+  size_t lds = 0;
+  if (dims->G > 0) lds = sizeof(float) * (((size_t)dims->S * dims->K * 9 + 3) & ~(size_t)3) +
+                         sizeof(float) * (size_t)dims->K * D4GS_PROJ_BLOCK;
+  if (lds > 64 * 1024) {
+    d4gs_set_error("S*K too large for the LDS-resident bases (S=%d K=%d)", dims->S, dims->K);
+    return D4GS_EINVAL;
+  }
+  const int blocks = (dims->N + D4GS_PROJ_BLOCK - 1) / D4GS_PROJ_BLOCK;
+  hipLaunchKernelGGL(k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
+  int rc = d4gs_check_launch("k_project_fwd");
+  if (rc) return rc;
+  const int sblocks = (int)((n_inst + SCAN_TILE - 1) / SCAN_TILE);
+  hipLaunchKernelGGL(k_scan_sums, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, n_inst,
+                     out->scan_ws);
+  hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, out->scan_ws, out->scan_ws, (int64_t)sblocks, 0,
+                     out->n_isect);
+  hipLaunchKernelGGL(k_scan_apply, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, out->scan_ws,
+                     n_inst, out->isect_offsets);
+  hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, out->tile_counts, out->tile_offsets, n_tiles, 1,
+                     (int64_t *)nullptr);
+  return d4gs_check_launch("scan");
+}

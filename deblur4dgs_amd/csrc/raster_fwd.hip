@@ -1,0 +1,169 @@
+// raster_fwd.hip -- per-tile front-to-back alpha compositing for all S exposure sub-samples.
+//
+// Replaces gsplat rasterize_to_pixels_fwd<CDIM> (+ the Python-side expected-depth division of
+// rasterization(render_mode="RGB+ED")); reference call site flow3d/scene_model.py:360-373.
+//
+// CDNA4 mapping: ONE wave64 per 16x16 tile, each lane owns a 2x2 pixel quad (4 pixels / lane):
+//   * the per-splat record is read once from LDS (broadcast ds_read_b128) and reused for 4 pixels, so the
+//     composite is VALU-bound, not LDS-bound, and per-splat loop overhead is amortised 4x;
+//   * a single-wave workgroup needs no cross-wave barrier: batches of 64 splats are staged by the wave's own
+//     64 lanes (one coalesced id load + one 32-B geom gather + the colour row per lane);
+//   * early exit is one ballot per 16 splats.
+// Block -> tile mapping is XCD-aware: consecutive logical tiles (same sub-sample, neighbouring tiles, shared
+// splats) land on the same XCD so the gathered records hit that XCD's L2.
+#include "common.h"
+
+namespace {
+
+struct RasterFwdArgs {
+  int N, S, width, height, tw, th;
+  int ed;  // divide the depth channel by max(alpha, 1e-10)
+  const float *geom;
+  const float *ctab;
+  const float *background;  // [D] or null
+  const int32_t *tile_offsets;
+  const int32_t *sorted_gid;
+  float *out;      // [S,H,W,NCH]
+  float *alphas;   // [S,H,W]
+  int32_t *last_ids;
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int n_blocks) {
+  const int per = (n_blocks + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
+  constexpr int NCH = D + (DEPTH ? 1 : 0);
+  constexpr int DP = (D + 3) & ~3;
+  constexpr int DV = DP / 4;
+  __shared__ float4 sg0[64];
+  __shared__ float4 sg1[64];
+  __shared__ float4 scol[64 * DV];
+
+  const int n_tiles_s = a.tw * a.th;
+  const int n_tiles = a.S * n_tiles_s;
+  const int t = xcd_remap(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
+  const int ty = tl / a.tw, tx = tl - ty * a.tw;
+  const int lane = threadIdx.x;
+  const int x0 = tx * D4GS_TILE + 2 * (lane & 7), y0 = ty * D4GS_TILE + 2 * (lane >> 3);
+
+  float pxf[4], pyf[4], T[4], acc[4][NCH];
+  int last[4];
+  bool done[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int x = x0 + (p & 1), y = y0 + (p >> 1);
+    pxf[p] = (float)x + 0.5f;
+    pyf[p] = (float)y + 0.5f;
+    T[p] = 1.f;
+    last[p] = 0;
+    done[p] = !(x < a.width && y < a.height);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) acc[p][c] = 0.f;
+  }
+
+  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
+  const size_t inst_base = (size_t)s * a.N;
+  for (int b = start; b < end; b += 64) {
+    if (__all(done[0] && done[1] && done[2] && done[3])) break;
+    __syncthreads();
+    const int idx = b + lane;
+    if (idx < end) {
+      const int gid = a.sorted_gid[idx];
+      const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
+      sg0[lane] = gp[0];
+      sg1[lane] = gp[1];
+      const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
+#pragma unroll
+      for (int v = 0; v < DV; v++) scol[lane * DV + v] = cp[v];
+    }
+    __syncthreads();
+    const int nb = min(64, end - b);
+    for (int j = 0; j < nb; j++) {
+      if ((j & 15) == 0 && j && __all(done[0] && done[1] && done[2] && done[3])) break;
+      const float4 g0 = sg0[j], g1 = sg1[j];
+      float col[DP];
+#pragma unroll
+      for (int v = 0; v < DV; v++) {
+        const float4 c4 = scol[j * DV + v];
+        col[v * 4] = c4.x, col[v * 4 + 1] = c4.y, col[v * 4 + 2] = c4.z, col[v * 4 + 3] = c4.w;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const float dx = g0.x - pxf[p], dy = g0.y - pyf[p];
+        const float sigma = 0.5f * (g1.x * dx * dx + g1.z * dy * dy) + g1.y * dx * dy;
+        const float alpha = fminf(0.999f, g0.z * __expf(-sigma));
+        bool valid = !done[p] && (sigma >= 0.f) && (alpha >= (1.f / 255.f));
+        const float nT = T[p] * (1.f - alpha);
+        const bool stop = valid && (nT <= 1e-4f);
+        done[p] = done[p] || stop;
+        valid = valid && !stop;
+        const float vis = valid ? alpha * T[p] : 0.f;
+#pragma unroll
+        for (int c = 0; c < D; c++) acc[p][c] += col[c] * vis;
+        if (DEPTH) acc[p][D] += g0.w * vis;
+        T[p] = valid ? nT : T[p];
+        last[p] = valid ? (b + j) : last[p];
+      }
+    }
+  }
+
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int x = x0 + (p & 1), y = y0 + (p >> 1);
+    if (x < a.width && y < a.height) {
+      const size_t pix = ((size_t)s * a.height + y) * a.width + x;
+      const float al = 1.f - T[p];
+      a.alphas[pix] = al;
+      a.last_ids[pix] = last[p];
+      float *o = a.out + pix * NCH;
+#pragma unroll
+      for (int c = 0; c < D; c++) o[c] = acc[p][c] + (a.background ? T[p] * a.background[c] : 0.f);
+      if (DEPTH) o[D] = a.ed ? acc[p][D] / fmaxf(al, 1e-10f) : acc[p][D];
+    }
+  }
+}
+
+template <int D, bool DEPTH>
+int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
+  const int n_tiles = a.S * a.tw * a.th;
+  const int blocks = ((n_tiles + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_raster_fwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+  return d4gs_check_launch("k_raster_fwd");
+}
+
+}  // namespace
+
+int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
+                         hipStream_t stream) {
+  RasterFwdArgs a;
+  a.N = dims->N, a.S = dims->S, a.width = dims->width, a.height = dims->height;
+  a.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
+  a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
+  a.ed = dims->depth_mode == D4GS_DEPTH_ED;
+  a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
+  a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid;
+  a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids;
+  const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
+#define D4GS_CASE(DD)                                                   \
+  case DD:                                                              \
+    return dep ? launch_fwd<DD, true>(a, stream) : launch_fwd<DD, false>(a, stream);
+  switch (dims->D) {
+    D4GS_CASE(1)
+    D4GS_CASE(2)
+    D4GS_CASE(3)
+    D4GS_CASE(4)
+    D4GS_CASE(5)
+    D4GS_CASE(8)
+    D4GS_CASE(16)
+    D4GS_CASE(32)
+    default:
+      d4gs_set_error("unsupported colour channel count D=%d (supported: 1,2,3,4,5,8,16,32; pad on the host)", dims->D);
+      return D4GS_EINVAL;
+  }
+#undef D4GS_CASE
+}

@@ -1,0 +1,225 @@
+"""Autograd plumbing around libd4gs.so: two `torch.autograd.Function`s that own allocation and enqueue the
+HIP kernels on torch's current stream.
+
+  ProjectFn   leaf params (+ bases, times, camera deltas, viewmat)  ->  means2d, conics, depths  [S,N,...],
+              activated opacities / colour table.   fwd: d4gs_project_fwd     bwd: d4gs_project_bwd
+  RasterFn    those per-instance tensors                            ->  render_colors [S,H,W,D'], alphas
+              fwd: d4gs_bin_sort + d4gs_raster_fwd                   bwd: d4gs_raster_bwd
+
+`means2d` is a real autograd intermediate between the two, so `means2d.retain_grad()` / `.grad` behave exactly as
+with gsplat's `info["means2d"]` (reference flow3d/scene_model.py:456-461, flow3d/trainer.py:975).
+
+PyTorch here is plumbing (device memory, streams, autograd graph); all arithmetic happens in the HIP library.
+There is no eager / CPU fallback: tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib as L
+
+
+@dataclass
+class RenderCfg:
+    N: int
+    G: int
+    K: int
+    T: int
+    S: int
+    D: int
+    width: int
+    height: int
+    depth_mode: int = L.DEPTH_NONE
+    flags: int = 0
+    n_sigmoid: int = 0
+    near_plane: float = 0.01
+    far_plane: float = 1e10
+    eps2d: float = 0.3
+    radius_clip: float = 0.0
+
+    @property
+    def DP(self) -> int:
+        return (self.D + 3) // 4 * 4
+
+    @property
+    def NCH(self) -> int:
+        return self.D + (1 if self.depth_mode != L.DEPTH_NONE else 0)
+
+    @property
+    def tiles(self) -> tuple[int, int]:
+        return (self.width + L.TILE - 1) // L.TILE, (self.height + L.TILE - 1) // L.TILE
+
+    def dims(self) -> L.Dims:
+        return L.Dims(self.N, self.G, self.K, self.T, self.S, self.D, self.width, self.height, self.depth_mode,
+                      self.flags, self.n_sigmoid, self.near_plane, self.far_plane, self.eps2d, self.radius_clip)
+
+
+@dataclass
+class State:
+    """Non-differentiable buffers shared by the two stages (all owned by torch)."""
+    cfg: RenderCfg
+    proj_in: dict = field(default_factory=dict)
+    proj_out: dict = field(default_factory=dict)
+    isect: dict = field(default_factory=dict)
+    raster: dict = field(default_factory=dict)
+    n_isect: int = -1
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("deblur4dgs_amd runs on an MI355X (ROCm) device only; got a CPU tensor (no CPU fallback)")
+
+
+def _f32c(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _proj_structs(st: State):
+    pin = L.fill(L.ProjIn(), **st.proj_in)
+    pout = L.fill(L.ProjOut(), **st.proj_out)
+    return pin, pout
+
+
+class ProjectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, st: State, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs,
+                viewmat, Kmat):
+        cfg = st.cfg
+        _need_gpu(means)
+        dev = means.device
+        S, N = cfg.S, cfg.N
+        tw, th = cfg.tiles
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        st.proj_in = dict(means=_f32c(means), quats=_f32c(quats), scales=_f32c(scales), opacities=_f32c(opacities),
+                          colors=_f32c(colors), motion_coefs=_f32c(motion_coefs), rots=_f32c(rots),
+                          transls=_f32c(transls), times=_f32c(times), RTs=_f32c(RTs), viewmat=_f32c(viewmat),
+                          Kmat=_f32c(Kmat))
+        lib = L.lib()
+        st.proj_out = dict(
+            means2d=torch.empty(S, N, 2, **f32), depths=torch.empty(S, N, **f32), conics=torch.empty(S, N, 3, **f32),
+            radii=torch.empty(S, N, **i32), opac_act=torch.empty(N, **f32), ctab=torch.empty(N, cfg.DP, **f32),
+            geom=torch.empty(S * N, L.GEOM_STRIDE, **f32), tiles_touched=torch.empty(S * N, **i32),
+            isect_offsets=torch.empty(S * N, **i32), tile_counts=torch.empty(S * tw * th, **i32),
+            tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(1, dtype=torch.int64, device=dev),
+            scan_ws=torch.empty(lib.d4gs_scan_ws_elems(S * N), **i32),
+        )
+        dims = cfg.dims()
+        pin, pout = _proj_structs(st)
+        L.check(lib.d4gs_project_fwd(C.byref(dims), C.byref(pin), C.byref(pout), _stream()), "d4gs_project_fwd")
+        ctx.st = st
+        ctx.needs = [t is not None and t.requires_grad for t in
+                     (means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat)]
+        o = st.proj_out
+        ctx.mark_non_differentiable(o["radii"])
+        return o["means2d"], o["conics"], o["depths"], o["opac_act"], o["ctab"], o["radii"]
+
+    @staticmethod
+    def backward(ctx, v_means2d, v_conics, v_depths, v_opac_act, v_ctab, _v_radii):
+        st: State = ctx.st
+        cfg = st.cfg
+        o = st.proj_out
+        dev = o["means2d"].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = lambda g, ref: torch.zeros_like(ref) if g is None else g.to(torch.float32).contiguous()
+        v_means2d, v_conics, v_depths = z(v_means2d, o["means2d"]), z(v_conics, o["conics"]), z(v_depths, o["depths"])
+        v_opac_act, v_ctab = z(v_opac_act, o["opac_act"]), z(v_ctab, o["ctab"])
+        lib = L.lib()
+        dims = cfg.dims()
+        pi = st.proj_in
+        dyn = cfg.G > 0
+        g = dict(
+            v_means=torch.empty(cfg.N, 3, **f32), v_quats=torch.empty(cfg.N, 4, **f32),
+            v_scales=torch.empty(cfg.N, 3, **f32), v_opacities=torch.empty(cfg.N, **f32),
+            v_colors=torch.empty(cfg.N, cfg.D, **f32),
+            v_motion_coefs=torch.empty(cfg.G, cfg.K, **f32) if dyn else None,
+            v_rots=torch.empty(cfg.K, cfg.T, 6, **f32) if dyn else None,
+            v_transls=torch.empty(cfg.K, cfg.T, 3, **f32) if dyn else None,
+            v_times=torch.empty(cfg.S, **f32) if dyn else None,
+            v_RTs=torch.empty(cfg.S, 3, 4, **f32) if pi["RTs"] is not None else None,
+            v_viewmat=torch.empty(4, 4, **f32),
+            partials=torch.empty(lib.d4gs_bwd_partials_elems(C.byref(dims)), **f32),
+        )
+        pin, pout = _proj_structs(st)
+        lg = L.fill(L.LeafGrads(), **g)
+        L.check(lib.d4gs_project_bwd(C.byref(dims), C.byref(pin), C.byref(pout), L.ptr(v_means2d), L.ptr(v_conics),
+                                     L.ptr(v_depths), L.ptr(v_opac_act), L.ptr(v_ctab), C.byref(lg), _stream()),
+                "d4gs_project_bwd")
+        outs = [g["v_means"], g["v_quats"], g["v_scales"], g["v_opacities"], g["v_colors"], g["v_motion_coefs"],
+                g["v_rots"], g["v_transls"], g["v_times"], g["v_RTs"], g["v_viewmat"]]
+        outs = [x if need else None for x, need in zip(outs, ctx.needs)]
+        return (None, *outs, None)
+
+
+class RasterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, st: State, means2d, conics, depths, opac_act, ctab, background):
+        cfg = st.cfg
+        dev = means2d.device
+        S, H, W = cfg.S, cfg.height, cfg.width
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        lib = L.lib()
+        n = int(st.proj_out["n_isect"].item())  # the one host sync of the forward pass (sizes the lists)
+        st.n_isect = n
+        m = max(n, 1)
+        st.isect = dict(keys=torch.empty(m, dtype=torch.int64, device=dev), gid_of_emit=torch.empty(m, **i32),
+                        sorted_gid=torch.empty(m, **i32), sorted_emit=torch.empty(m, **i32))
+        st.raster = dict(background=_f32c(background), render_colors=torch.empty(S, H, W, cfg.NCH, **f32),
+                         render_alphas=torch.empty(S, H, W, **f32), last_ids=torch.empty(S, H, W, **i32))
+        dims = cfg.dims()
+        _, pout = _proj_structs(st)
+        isect = L.fill(L.Isect(), **st.isect)
+        isect.n_isect = n
+        ras = L.fill(L.Raster(), **st.raster)
+        L.check(lib.d4gs_bin_sort(C.byref(dims), C.byref(pout), C.byref(isect), _stream()), "d4gs_bin_sort")
+        L.check(lib.d4gs_raster_fwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), _stream()),
+                "d4gs_raster_fwd")
+        ctx.st = st
+        return st.raster["render_colors"], st.raster["render_alphas"].unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, v_colors, v_alphas):
+        st: State = ctx.st
+        cfg = st.cfg
+        dev = st.raster["render_colors"].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        lib = L.lib()
+        S, N = cfg.S, cfg.N
+        if v_colors is None:
+            v_colors = torch.zeros_like(st.raster["render_colors"])
+        v_colors = v_colors.to(torch.float32).contiguous()
+        v_alphas = None if v_alphas is None else v_alphas.to(torch.float32).contiguous()
+        g = dict(
+            v_render_colors=v_colors, v_render_alphas=v_alphas,
+            isect_grad=torch.empty(max(st.n_isect, 1), 6 + cfg.NCH, **f32),
+            v_means2d=torch.empty(S, N, 2, **f32), v_conics=torch.empty(S, N, 3, **f32),
+            v_depths=torch.zeros(S, N, **f32), v_opac_act=torch.empty(N, **f32), v_ctab=torch.empty(N, cfg.DP, **f32),
+        )
+        dims = cfg.dims()
+        _, pout = _proj_structs(st)
+        isect = L.fill(L.Isect(), **st.isect)
+        isect.n_isect = st.n_isect
+        ras = L.fill(L.Raster(), **st.raster)
+        rg = L.fill(L.RasterGrads(), **g)
+        L.check(lib.d4gs_raster_bwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), C.byref(rg), _stream()),
+                "d4gs_raster_bwd")
+        return None, g["v_means2d"], g["v_conics"], g["v_depths"], g["v_opac_act"], g["v_ctab"], None
+
+
+def render_instances(cfg: RenderCfg, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs,
+                     viewmat, Kmat, background):
+    """Deform + project + bin + sort + composite all S sub-samples.
+    -> render_colors [S,H,W,D'], render_alphas [S,H,W,1], means2d [S,N,2], radii int32 [S,N], state."""
+    st = State(cfg)
+    means2d, conics, depths, opac_act, ctab, radii = ProjectFn.apply(
+        st, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat, Kmat)
+    rc, ra = RasterFn.apply(st, means2d, conics, depths, opac_act, ctab, background)
+    return rc, ra, means2d, radii, st

@@ -1,0 +1,173 @@
+/* d4gs.h -- C ABI of libd4gs.so: MI355X-native (gfx950) 4D-Gaussian exposure rasterizer.
+ *
+ * Drop-in boundary for ONE path of ZcsrenlongZ/Deblur4DGS: everything `SceneModel.render`
+ * (reference flow3d/scene_model.py:162-487) does on the device for one blurry frame --
+ *   per-Gaussian activations            flow3d/params.py:39-43,70-84
+ *   motion-basis deformation            flow3d/params.py:142-180, flow3d/transforms.py:41-53
+ *   pose compose + camera delta         flow3d/scene_model.py:67-120,352-353
+ *   gsplat.rendering.rasterization      flow3d/scene_model.py:360-373  (gsplat==1.1.1, packed=False)
+ *   exposure blend                      flow3d/scene_model.py:386-397
+ * forward and backward.  The reference reaches that code through Python (torch autograd + the gsplat
+ * CUDA extension); there is no C interface in the reference to copy, so the entry points below are what a
+ * ctypes / pybind binding of this path binds (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *  - plain C, no torch types; every pointer is a DEVICE pointer unless marked [host].
+ *  - the library never allocates, frees or synchronises: outputs and scratch are caller-provided,
+ *    every call only enqueues work on `stream` (a hipStream_t passed as void*).
+ *  - return 0 on success, negative D4GS_E* on error; message via d4gs_last_error() (thread-local).
+ *  - all floating point is fp32; matrices are row-major; quaternions are wxyz.
+ *  - instance index i = s*N + g (sub-sample s, Gaussian g); the first G Gaussians are dynamic.
+ */
+#ifndef D4GS_H
+#define D4GS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D4GS_VERSION 100
+#define D4GS_TILE 16
+#define D4GS_GEOM_STRIDE 8 /* floats per instance record: x, y, opacity, depth, conic a, b, c, pad */
+
+enum {
+  D4GS_OK = 0,
+  D4GS_EINVAL = -1,     /* bad argument / unsupported shape */
+  D4GS_ELAUNCH = -2,    /* hipLaunch / runtime error (message holds hipGetErrorString) */
+  D4GS_ECAPACITY = -3   /* caller-provided buffer too small */
+};
+
+enum { /* D4gsDims.flags */
+  D4GS_RAW_PARAMS = 1,  /* quats/scales/opacities/motion_coefs are raw leaves: apply normalize/exp/sigmoid/softmax
+                           (params.py:39-43).  When clear, scales/opacities are used as given (gsplat seam). */
+  D4GS_RAW_COLORS = 2   /* the first `n_sigmoid` colour channels are raw: apply sigmoid (params.py:40) */
+};
+
+enum { D4GS_DEPTH_NONE = 0, D4GS_DEPTH_ED = 1, D4GS_DEPTH_D = 2 }; /* render_mode RGB / RGB+ED / RGB+D */
+
+typedef struct D4gsDims {
+  int32_t N;          /* Gaussians */
+  int32_t G;          /* dynamic Gaussians (deformed by the motion bases); 0 = static scene */
+  int32_t K;          /* motion bases */
+  int32_t T;          /* frames per basis */
+  int32_t S;          /* exposure sub-samples in this call */
+  int32_t D;          /* colour channels supplied by the caller (without the depth channel) */
+  int32_t width, height;
+  int32_t depth_mode; /* D4GS_DEPTH_* ; channels rendered = D + (depth_mode != 0) */
+  int32_t flags;      /* D4GS_RAW_* */
+  int32_t n_sigmoid;  /* with D4GS_RAW_COLORS: channels [0,n_sigmoid) get sigmoid */
+  float near_plane, far_plane, eps2d, radius_clip; /* gsplat defaults 0.01, 1e10, 0.3, 0 */
+} D4gsDims;
+
+/* leaf inputs of the deform+project stage */
+typedef struct D4gsProjIn {
+  const float *means;        /* [N,3] */
+  const float *quats;        /* [N,4] wxyz */
+  const float *scales;       /* [N,3] */
+  const float *opacities;    /* [N]   */
+  const float *colors;       /* [N,D] row-major, or NULL if every channel is generated (mask) */
+  const float *motion_coefs; /* [G,K] or NULL */
+  const float *rots;         /* [K,T,6] or NULL */
+  const float *transls;      /* [K,T,3] or NULL */
+  const float *times;        /* [S] exposure times (frame units); ignored when G == 0 */
+  const float *RTs;          /* [S,3,4] camera deltas, or NULL = identity */
+  const float *viewmat;      /* [4,4] world->camera */
+  const float *Kmat;         /* [3,3] intrinsics */
+} D4gsProjIn;
+
+/* per-instance outputs + binning counters produced by d4gs_project_fwd */
+typedef struct D4gsProjOut {
+  float *means2d;          /* [S,N,2] pixel units */
+  float *depths;           /* [S,N]   */
+  float *conics;           /* [S,N,3] */
+  int32_t *radii;          /* [S,N]  >0 <=> visible */
+  float *opac_act;         /* [N]    activated opacity */
+  float *ctab;             /* [N,DP] activated colour table, DP = 4*ceil(D/4) */
+  float *geom;             /* [S*N,8] packed raster record */
+  int32_t *tiles_touched;  /* [S*N] */
+  int32_t *isect_offsets;  /* [S*N] exclusive scan of tiles_touched */
+  int32_t *tile_counts;    /* [S*tiles] splats per tile (consumed as cursors by d4gs_bin_sort) */
+  int32_t *tile_offsets;   /* [S*tiles+1] exclusive scan of tile_counts */
+  int64_t *n_isect;        /* [1] total intersections (read back by the host to size the next stage) */
+  int32_t *scan_ws;        /* [d4gs_scan_ws_elems(S*N)] scratch */
+} D4gsProjOut;
+
+typedef struct D4gsIsect {
+  int64_t n_isect;         /* [host] value read back from D4gsProjOut.n_isect */
+  uint64_t *keys;          /* [n_isect] scratch: (depth bits << 32 | emission index) per tile slot */
+  int32_t *gid_of_emit;    /* [n_isect] Gaussian id of each emission index */
+  int32_t *sorted_gid;     /* [n_isect] per-tile depth-sorted Gaussian ids (flatten_ids) */
+  int32_t *sorted_emit;    /* [n_isect] emission index of each sorted slot */
+} D4gsIsect;
+
+typedef struct D4gsRaster {
+  const float *background; /* [D] or NULL (depth channel's background is 0) */
+  float *render_colors;    /* [S,H,W,D+depth] */
+  float *render_alphas;    /* [S,H,W] */
+  int32_t *last_ids;       /* [S,H,W] index (into sorted_gid) of the last composited splat */
+} D4gsRaster;
+
+/* gradients w.r.t. the raster stage's per-instance inputs */
+typedef struct D4gsRasterGrads {
+  const float *v_render_colors; /* [S,H,W,D+depth] */
+  const float *v_render_alphas; /* [S,H,W] or NULL */
+  float *isect_grad;            /* [n_isect, 6+D+depth] scratch (zero-filled by the call) */
+  float *v_means2d;             /* [S,N,2]  (= means2d.grad contract, trainer.py:975) */
+  float *v_conics;              /* [S,N,3] */
+  float *v_depths;              /* [S,N]   (only written when depth_mode != 0) */
+  float *v_opac_act;            /* [N]     summed over S */
+  float *v_ctab;                /* [N,DP]  summed over S */
+} D4gsRasterGrads;
+
+/* leaf gradients produced by d4gs_project_bwd (all overwritten, not accumulated) */
+typedef struct D4gsLeafGrads {
+  float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors; /* [N,3] [N,4] [N,3] [N] [N,D] */
+  float *v_motion_coefs; /* [G,K] or NULL */
+  float *v_rots;         /* [K,T,6] or NULL */
+  float *v_transls;      /* [K,T,3] or NULL */
+  float *v_times;        /* [S] or NULL */
+  float *v_RTs;          /* [S,3,4] or NULL */
+  float *v_viewmat;      /* [4,4] or NULL (test-time pose optimisation, validator.py:437-452) */
+  float *partials;       /* [d4gs_bwd_partials_elems(dims)] scratch for the deterministic 2-level reduction */
+} D4gsLeafGrads;
+
+int d4gs_version(void);
+const char *d4gs_last_error(void);
+size_t d4gs_scan_ws_elems(int64_t n_instances);
+size_t d4gs_bwd_partials_elems(const D4gsDims *dims);
+
+/* a1-a6 + projection + tile counting + scans.  Replaces params.py:39-43,142-180, transforms.py:41-53,
+ * scene_model.py:67-120,352-353 and gsplat fully_fused_projection_fwd + isect_tiles pass 1 for all S. */
+int d4gs_project_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, void *stream);
+
+/* isect_tiles pass 2 + per-tile depth sort (replaces gsplat isect_tiles / radix sort / isect_offset_encode). */
+int d4gs_bin_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, void *stream);
+
+/* rasterize_to_pixels_fwd for all S sub-samples (+ expected-depth normalisation when depth_mode == ED). */
+int d4gs_raster_fwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
+                    void *stream);
+
+/* rasterize_to_pixels_bwd + per-instance gather of the per-intersection gradients (deterministic, no float atomics). */
+int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
+                    const D4gsRasterGrads *g, void *stream);
+
+/* fully_fused_projection_bwd + deformation / activation adjoints for all S, reduced to leaf gradients. */
+int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *proj,
+                     const float *v_means2d, const float *v_conics, const float *v_depths, const float *v_opac_act,
+                     const float *v_ctab, const D4gsLeafGrads *grads, void *stream);
+
+/* a9 exposure blend (scene_model.py:386-397): out = mean_S; policy[c] 1 -> max over {raw_0..raw_{S-2}, mean},
+ * 2 -> min over the same set (the reference's in-place quirk); acc = mean_S alphas. */
+int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] [C] */,
+                   const float *renders /* [S,P,C] */, const float *alphas /* [S,P] */, float *out /* [P,C] */,
+                   float *acc /* [P] */, void *stream);
+int d4gs_blend_bwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] */, const float *renders,
+                   const float *out, const float *v_out, const float *v_acc, float *v_renders /* [S,P,C] */,
+                   float *v_alphas /* [S,P] */, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D4GS_H */
