@@ -80,6 +80,15 @@ def lib() -> C.CDLL:
         L.d4gs_scan_ws_elems.argtypes = [C.c_int64]
         L.d4gs_bwd_partials_elems.restype = C.c_size_t
         L.d4gs_bwd_partials_elems.argtypes = [C.POINTER(Dims)]
+        P = C.POINTER
+        vp = C.c_void_p
+        L.d4gs_project_fwd.argtypes = [P(Dims), P(ProjIn), P(ProjOut), vp]
+        L.d4gs_bin_sort.argtypes = [P(Dims), P(ProjOut), P(Isect), vp]
+        L.d4gs_raster_fwd.argtypes = [P(Dims), P(ProjOut), P(Isect), P(Raster), vp]
+        L.d4gs_raster_bwd.argtypes = [P(Dims), P(ProjOut), P(Isect), P(Raster), P(RasterGrads), vp]
+        L.d4gs_project_bwd.argtypes = [P(Dims), P(ProjIn), P(ProjOut), vp, vp, vp, vp, vp, P(LeafGrads), vp]
+        L.d4gs_blend_fwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp]
+        L.d4gs_blend_bwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp, vp, vp]
         if L.d4gs_version() != 100:
             raise RuntimeError(f"libd4gs.so version {L.d4gs_version()} != 100 (stale build?)")
         _lib = L

@@ -1,0 +1,307 @@
+// raster_bwd.hip -- adjoint of the per-tile composite for all S sub-samples, plus the per-instance gather.
+//
+// Replaces gsplat rasterize_to_pixels_bwd<CDIM> (back-to-front replay, warp-reduce + atomicAdd into
+// v_means2d / v_conics / v_colors / v_opacities) and the autograd of the RGB+ED division.
+// Reference: the backward of flow3d/scene_model.py:360-373, driven by flow3d/trainer.py:231.
+//
+// CDNA4 mapping
+//   * one wave64 per 16x16 tile, 2x2 pixels per lane (same mapping as the forward): each splat's contribution
+//     is first summed over the lane's 4 pixels in registers, then over the wave with 6 DPP adds per value.
+//   * NO float atomics: the wave's reduced gradient row (x, y, conic a/b/c, opacity, colours, depth) is written to
+//     a per-INTERSECTION buffer at the splat's emission index.  Rows of one Gaussian instance are contiguous there,
+//     so k_gather sums them with plain loads in a fixed order -> bitwise reproducible gradients, and no
+//     fabric-level atomic traffic (device-scope float atomics are serialised memory-side on MI355X's 8 XCDs).
+#include "common.h"
+
+namespace {
+
+struct RasterBwdArgs {
+  int N, S, width, height, tw, th;
+  int ed;
+  const float *geom;
+  const float *ctab;
+  const float *background;
+  const int32_t *tile_offsets;
+  const int32_t *sorted_gid;
+  const int32_t *sorted_emit;
+  const float *out;     // forward render_colors (needed to undo the ED division)
+  const float *alphas;
+  const int32_t *last_ids;
+  const float *v_out;
+  const float *v_alphas;  // may be null
+  float *isect_grad;
+};
+
+__device__ __forceinline__ int xcd_remap_b(int b, int n_blocks) {
+  const int per = (n_blocks + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
+  constexpr int NCH = D + (DEPTH ? 1 : 0);
+  constexpr int DP = (D + 3) & ~3;
+  constexpr int DV = DP / 4;
+  constexpr int R = 6 + NCH;
+  constexpr int RP = R | 1;  // odd LDS row stride
+  __shared__ float4 sg0[64];
+  __shared__ float4 sg1[64];
+  __shared__ float4 scol[64 * DV];
+  __shared__ float sgrad[64 * RP];
+
+  const int n_tiles_s = a.tw * a.th;
+  const int n_tiles = a.S * n_tiles_s;
+  const int t = xcd_remap_b(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
+  if (end <= start) return;
+  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
+  const int ty = tl / a.tw, tx = tl - ty * a.tw;
+  const int lane = threadIdx.x;
+  const int x0 = tx * D4GS_TILE + 2 * (lane & 7), y0 = ty * D4GS_TILE + 2 * (lane >> 3);
+
+  float pxf[4], pyf[4], T[4], Tfin[4], va[4], vo[4][NCH], buf[4][NCH];
+  int last[4];
+  int hi = start - 1;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int x = x0 + (p & 1), y = y0 + (p >> 1);
+    const bool inside = x < a.width && y < a.height;
+    pxf[p] = (float)x + 0.5f;
+    pyf[p] = (float)y + 0.5f;
+    last[p] = -1;
+    Tfin[p] = 1.f;
+    va[p] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) vo[p][c] = 0.f, buf[p][c] = 0.f;
+    if (inside) {
+      const size_t pix = ((size_t)s * a.height + y) * a.width + x;
+      last[p] = a.last_ids[pix];
+      const float al = a.alphas[pix];
+      Tfin[p] = 1.f - al;
+      const float *vp = a.v_out + pix * NCH;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) vo[p][c] = vp[c];
+      float v_al = a.v_alphas ? a.v_alphas[pix] : 0.f;
+      if (DEPTH && a.ed) {  // out_d = raw_d / max(alpha, 1e-10)
+        const float den = fmaxf(al, 1e-10f);
+        const float vd = vo[p][D];
+        if (al >= 1e-10f) v_al -= vd * a.out[pix * NCH + D] / den;  // raw_d / den^2 = out_d / den
+        vo[p][D] = vd / den;
+      }
+      float bgdot = 0.f;
+      if (a.background) {
+#pragma unroll
+        for (int c = 0; c < D; c++) bgdot += a.background[c] * vo[p][c];
+      }
+      va[p] = Tfin[p] * (v_al - bgdot);  // both terms carry T_final * ra
+      hi = max(hi, last[p]);
+    }
+    T[p] = Tfin[p];
+  }
+  hi = min(wave_max_i(hi), end - 1);
+  const size_t inst_base = (size_t)s * a.N;
+
+  for (int bh = hi; bh >= start; bh -= 64) {
+    __syncthreads();
+    const int idx = bh - lane;
+    int emit = -1;
+    if (idx >= start) {
+      const int gid = a.sorted_gid[idx];
+      emit = a.sorted_emit[idx];
+      const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
+      sg0[lane] = gp[0];
+      sg1[lane] = gp[1];
+      const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
+#pragma unroll
+      for (int v = 0; v < DV; v++) scol[lane * DV + v] = cp[v];
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) sgrad[lane * RP + r] = 0.f;
+    __syncthreads();
+    const int nb = min(64, bh - start + 1);
+    for (int j = 0; j < nb; j++) {
+      const int cur = bh - j;
+      const float4 g0 = sg0[j], g1 = sg1[j];
+      float dx[4], dy[4], vis[4], alpha[4];
+      bool valid[4];
+      bool any = false;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        dx[p] = g0.x - pxf[p];
+        dy[p] = g0.y - pyf[p];
+        const float sigma = 0.5f * (g1.x * dx[p] * dx[p] + g1.z * dy[p] * dy[p]) + g1.y * dx[p] * dy[p];
+        vis[p] = __expf(-sigma);
+        alpha[p] = fminf(0.999f, g0.z * vis[p]);
+        valid[p] = (cur <= last[p]) && (sigma >= 0.f) && (alpha[p] >= (1.f / 255.f));
+        any = any || valid[p];
+      }
+      if (!__any(any)) continue;
+      float col[NCH];
+#pragma unroll
+      for (int v = 0; v < DV; v++) {
+        const float4 c4 = scol[j * DV + v];
+        if (v * 4 < D) col[v * 4] = c4.x;
+        if (v * 4 + 1 < D) col[v * 4 + 1] = c4.y;
+        if (v * 4 + 2 < D) col[v * 4 + 2] = c4.z;
+        if (v * 4 + 3 < D) col[v * 4 + 3] = c4.w;
+      }
+      if (DEPTH) col[D] = g0.w;
+      float gx = 0.f, gy = 0.f, ga = 0.f, gb = 0.f, gc = 0.f, go = 0.f, gcol[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) gcol[c] = 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        if (valid[p]) {
+          const float ra = 1.f / (1.f - alpha[p]);
+          T[p] *= ra;
+          const float fac = alpha[p] * T[p];
+          float v_alpha = 0.f;
+#pragma unroll
+          for (int c = 0; c < NCH; c++) {
+            gcol[c] += fac * vo[p][c];
+            v_alpha += (col[c] * T[p] - buf[p][c] * ra) * vo[p][c];
+            buf[p][c] += col[c] * fac;
+          }
+          v_alpha += va[p] * ra;
+          if (g0.z * vis[p] <= 0.999f) {
+            const float v_sigma = -g0.z * vis[p] * v_alpha;
+            ga += 0.5f * v_sigma * dx[p] * dx[p];
+            gb += v_sigma * dx[p] * dy[p];
+            gc += 0.5f * v_sigma * dy[p] * dy[p];
+            gx += v_sigma * (g1.x * dx[p] + g1.y * dy[p]);
+            gy += v_sigma * (g1.y * dx[p] + g1.z * dy[p]);
+            go += vis[p] * v_alpha;
+          }
+        }
+      }
+      gx = wave_sum_to_lane63(gx);
+      gy = wave_sum_to_lane63(gy);
+      ga = wave_sum_to_lane63(ga);
+      gb = wave_sum_to_lane63(gb);
+      gc = wave_sum_to_lane63(gc);
+      go = wave_sum_to_lane63(go);
+#pragma unroll
+      for (int c = 0; c < NCH; c++) gcol[c] = wave_sum_to_lane63(gcol[c]);
+      if (lane == 63) {
+        float *row = sgrad + j * RP;
+        row[0] = gx, row[1] = gy, row[2] = ga, row[3] = gb, row[4] = gc, row[5] = go;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) row[6 + c] = gcol[c];
+      }
+    }
+    __syncthreads();
+    if (emit >= 0) {
+      float *dst = a.isect_grad + (size_t)emit * R;
+#pragma unroll
+      for (int r = 0; r < R; r++) dst[r] = sgrad[lane * RP + r];
+    }
+  }
+}
+
+// one lane per Gaussian, looping over sub-samples: sums the contiguous per-intersection rows of each instance
+struct GatherArgs {
+  int N, S, D, DP, depth;
+  const int32_t *tiles_touched;
+  const int32_t *isect_offsets;
+  const float *isect_grad;
+  float *v_means2d, *v_conics, *v_depths, *v_opac_act, *v_ctab;
+};
+
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) k_gather(const GatherArgs a) {
+  constexpr int NCH = D + (DEPTH ? 1 : 0);
+  constexpr int DP = (D + 3) & ~3;
+  constexpr int R = 6 + NCH;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.N) return;
+  float vo = 0.f, vc[D];
+#pragma unroll
+  for (int c = 0; c < D; c++) vc[c] = 0.f;
+  for (int s = 0; s < a.S; s++) {
+    const size_t i = (size_t)s * a.N + g;
+    const int cnt = a.tiles_touched[i];
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.f;
+    const float *row = a.isect_grad + (size_t)a.isect_offsets[i] * R;
+    for (int k = 0; k < cnt; k++, row += R) {
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] += row[r];
+    }
+    *reinterpret_cast<float2 *>(a.v_means2d + i * 2) = make_float2(acc[0], acc[1]);
+    a.v_conics[i * 3] = acc[2];
+    a.v_conics[i * 3 + 1] = acc[3];
+    a.v_conics[i * 3 + 2] = acc[4];
+    vo += acc[5];
+#pragma unroll
+    for (int c = 0; c < D; c++) vc[c] += acc[6 + c];
+    if (DEPTH) a.v_depths[i] = acc[6 + D];
+  }
+  a.v_opac_act[g] = vo;
+#pragma unroll
+  for (int c = 0; c < DP; c++) a.v_ctab[(size_t)g * DP + c] = c < D ? vc[c < D ? c : 0] : 0.f;
+}
+
+template <int D, bool DEPTH>
+int launch_bwd(const RasterBwdArgs &a, const GatherArgs &ga, int64_t n_isect, hipStream_t stream) {
+  constexpr int R = 6 + D + (DEPTH ? 1 : 0);
+  hipError_t e = hipMemsetAsync(a.isect_grad, 0, sizeof(float) * (size_t)R * (size_t)(n_isect > 0 ? n_isect : 1), stream);
+  if (e != hipSuccess) {
+    d4gs_set_error("hipMemsetAsync(isect_grad): %s", hipGetErrorString(e));
+    return D4GS_ELAUNCH;
+  }
+  const int n_tiles = a.S * a.tw * a.th;
+  const int blocks = ((n_tiles + 7) / 8) * 8;
+  if (n_isect > 0) {
+    hipLaunchKernelGGL((k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+    int rc = d4gs_check_launch("k_raster_bwd");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL((k_gather<D, DEPTH>), dim3((ga.N + 255) / 256), dim3(256), 0, stream, ga);
+  return d4gs_check_launch("k_gather");
+}
+
+}  // namespace
+
+int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
+                         const D4gsRasterGrads *g, hipStream_t stream) {
+  RasterBwdArgs a;
+  a.N = dims->N, a.S = dims->S, a.width = dims->width, a.height = dims->height;
+  a.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
+  a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
+  a.ed = dims->depth_mode == D4GS_DEPTH_ED;
+  a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
+  a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.sorted_emit = isect->sorted_emit;
+  a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids;
+  a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad;
+  GatherArgs ga;
+  ga.N = dims->N, ga.S = dims->S, ga.D = dims->D, ga.DP = (dims->D + 3) & ~3;
+  ga.depth = dims->depth_mode != D4GS_DEPTH_NONE;
+  ga.tiles_touched = proj->tiles_touched, ga.isect_offsets = proj->isect_offsets, ga.isect_grad = g->isect_grad;
+  ga.v_means2d = g->v_means2d, ga.v_conics = g->v_conics, ga.v_depths = g->v_depths, ga.v_opac_act = g->v_opac_act;
+  ga.v_ctab = g->v_ctab;
+  const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
+#define D4GS_CASE(DD)                                                                             \
+  case DD:                                                                                        \
+    return dep ? launch_bwd<DD, true>(a, ga, isect->n_isect, stream) : launch_bwd<DD, false>(a, ga, isect->n_isect, stream);
+  switch (dims->D) {
+    D4GS_CASE(1)
+    D4GS_CASE(2)
+    D4GS_CASE(3)
+    D4GS_CASE(4)
+    D4GS_CASE(5)
+    D4GS_CASE(8)
+    D4GS_CASE(16)
+    default:
+      d4gs_set_error("unsupported colour channel count D=%d", dims->D);
+      return D4GS_EINVAL;
+  }
+#undef D4GS_CASE
+}

@@ -149,8 +149,9 @@ class ProjectFn(torch.autograd.Function):
         )
         pin, pout = _proj_structs(st)
         lg = L.fill(L.LeafGrads(), **g)
-        L.check(lib.d4gs_project_bwd(C.byref(dims), C.byref(pin), C.byref(pout), L.ptr(v_means2d), L.ptr(v_conics),
-                                     L.ptr(v_depths), L.ptr(v_opac_act), L.ptr(v_ctab), C.byref(lg), _stream()),
+        vp = lambda t: C.c_void_p(L.ptr(t))  # bare Python ints would be truncated to 32-bit C ints
+        L.check(lib.d4gs_project_bwd(C.byref(dims), C.byref(pin), C.byref(pout), vp(v_means2d), vp(v_conics),
+                                     vp(v_depths), vp(v_opac_act), vp(v_ctab), C.byref(lg), _stream()),
                 "d4gs_project_bwd")
         outs = [g["v_means"], g["v_quats"], g["v_scales"], g["v_opacities"], g["v_colors"], g["v_motion_coefs"],
                 g["v_rots"], g["v_transls"], g["v_times"], g["v_RTs"], g["v_viewmat"]]

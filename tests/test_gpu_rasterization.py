@@ -87,3 +87,44 @@ def test_empty_and_degenerate():
     assert info["n_isect"] == 0 and (info["radii"] == 0).all()
     assert torch.allclose(rc, torch.tensor([0.25, 0.5, 0.75], device=dev).expand(1, H, W, 3))
     assert (ra == 0).all()
+
+
+@pytest.mark.parametrize("mode,D,N,W,H", [("RGB", 3, 2500, 128, 80), ("RGB+ED", 3, 2500, 128, 80),
+                                          ("RGB+ED", 16, 1200, 80, 64), ("RGB+ED", 4, 1500, 96, 50)])
+def test_backward_matches_oracle(mode, D, N, W, H):
+    inp = static_inputs(N, W, H, seed=200 + D, dtype=torch.float64, D=D)
+    bg = torch.linspace(0.1, 0.9, D, dtype=torch.float64)
+    t = {k: v.clone().requires_grad_(k != "K") for k, v in inp.items()}
+    ref_c, ref_a, ref_info = raster.rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"],
+                                                  t["K"], W, H, background=bg, render_mode=mode)
+    g = torch.Generator().manual_seed(9)
+    w_c = torch.randn(ref_c.shape, generator=g, dtype=torch.float64)
+    w_a = torch.randn(ref_a.shape, generator=g, dtype=torch.float64)
+    ref_info["means2d"].retain_grad()
+    ((ref_c * w_c).sum() + (ref_a * w_a).sum()).backward()
+
+    rc, ra, info, tg = _run_gpu(inp, W, H, mode, bg, requires_grad=True)
+    info["means2d"].retain_grad()
+    dev = rc.device
+    ((rc[0] * w_c.to(dev).float()).sum() + (ra[0] * w_a.to(dev).float()).sum()).backward()
+    torch.cuda.synchronize()
+    # the means2d.grad contract (trainer.py:975)
+    assert frac_bad(info["means2d"].grad[0].cpu(), ref_info["means2d"].grad, 1e-3) < 2e-3
+    for name in ("means", "quats", "scales", "opac", "colors"):
+        got, ref = tg[name].grad.cpu(), t[name].grad
+        assert frac_bad(got, ref, 1e-3) < 3e-3, (name, rel_err(got, ref))
+    got, ref = tg["V"].grad.cpu()[:3], t["V"].grad[:3]
+    assert rel_err(got, ref) < 2e-3, ("viewmat", rel_err(got, ref))
+
+
+def test_backward_is_deterministic():
+    W, H, N = 96, 64, 2000
+    inp = static_inputs(N, W, H, seed=5, dtype=torch.float32)
+    grads = []
+    for _ in range(2):
+        rc, ra, info, tg = _run_gpu(inp, W, H, "RGB+ED", torch.ones(3), requires_grad=True)
+        (rc.square().sum() + ra.sum()).backward()
+        torch.cuda.synchronize()
+        grads.append([tg[k].grad.clone() for k in ("means", "quats", "scales", "opac", "colors", "V")])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)  # no float atomics anywhere -> bitwise reproducible
