@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
                 "Build it with `python -m deblur4dgs_amd.build` (hipcc, --offload-arch=gfx950)."
             )
+        import torch  # noqa: F401  -- torch's bundled HIP runtime must be the one both sides use: load it first
         L = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(L, name)  # AttributeError if the symbol is missing

@@ -129,7 +129,7 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
   e.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   const int64_t n_inst = (int64_t)dims->S * dims->N;
-  hipLaunchKernelGGL(k_emit, dim3((unsigned)((n_inst + 255) / 256)), dim3(256), 0, stream, e);
+  D4GS_LAUNCH("k_emit", k_emit, dim3((unsigned)((n_inst + 255) / 256)), dim3(256), 0, stream, e);
   int rc = d4gs_check_launch("k_emit");
   if (rc) return rc;
   const int n_tiles = dims->S * e.tw * e.th;
@@ -143,6 +143,6 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
     (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_tile_sort, dim3(n_tiles), dim3(256), (size_t)cap * 8, stream, s);
+  D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(256), (size_t)cap * 8, stream, s);
   return d4gs_check_launch("k_tile_sort");
 }

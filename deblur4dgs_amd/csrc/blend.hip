@@ -78,7 +78,7 @@ int d4gs_blend_fwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, 
     return D4GS_EINVAL;
   }
   for (int c = 0; c < 64; c++) pol.p[c] = (c < C && policy) ? (int8_t)policy[c] : 0;
-  hipLaunchKernelGGL(k_blend_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders,
+  D4GS_LAUNCH("k_blend_fwd", k_blend_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders,
                      alphas, out, acc);
   return d4gs_check_launch("k_blend_fwd");
 }
@@ -92,7 +92,7 @@ int d4gs_blend_bwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, 
     return D4GS_EINVAL;
   }
   for (int c = 0; c < 64; c++) pol.p[c] = (c < C && policy) ? (int8_t)policy[c] : 0;
-  hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders,
+  D4GS_LAUNCH("k_blend_bwd", k_blend_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders,
                      out, v_out, v_acc, v_renders, v_alphas);
   return d4gs_check_launch("k_blend_bwd");
 }

@@ -18,6 +18,36 @@ int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float 
 
 static thread_local char g_err[512] = "";
 
+// ---- per-kernel event profiler -------------------------------------------------------------------------
+#include <mutex>
+#include <string>
+#include <vector>
+namespace {
+struct ProfRec {
+  const char *name;
+  hipEvent_t a, b;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
+}  // namespace
+
+ProfScope::ProfScope(const char *name, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  r.name = name;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, s);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(g_prof[slot].b, stream);
+}
+
 void d4gs_set_error(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -53,6 +83,38 @@ static int check_dims(const D4gsDims *d) {
 extern "C" {
 
 int d4gs_version(void) { return D4GS_VERSION; }
+
+void d4gs_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+}
+
+/* Waits for the recorded events, writes "name count total_ms\n" per kernel into buf, clears the records. */
+int d4gs_profile_collect(char *buf, size_t cap) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  struct Agg { std::string name; int n; double ms; };
+  std::vector<Agg> agg;
+  for (auto &r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      bool found = false;
+      for (auto &x : agg)
+        if (x.name == r.name) { x.n++, x.ms += ms; found = true; break; }
+      if (!found) agg.push_back({r.name, 1, ms});
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  size_t off = 0;
+  for (auto &x : agg) {
+    int w = snprintf(buf + off, off < cap ? cap - off : 0, "%s %d %.6f\n", x.name.c_str(), x.n, x.ms);
+    if (w < 0 || off + (size_t)w >= cap) break;
+    off += (size_t)w;
+  }
+  if (cap) buf[off < cap ? off : cap - 1] = 0;
+  return (int)agg.size();
+}
 const char *d4gs_last_error(void) { return g_err; }
 
 int d4gs_project_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, void *stream) {

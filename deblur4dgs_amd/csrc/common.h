@@ -197,3 +197,16 @@ __device__ __forceinline__ float wave_sum_to_lane63(float x) {
 __device__ __forceinline__ float wave_sum(float x) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(x)), 63));
 }
+
+// Optional per-kernel HIP-event profiler (off by default; used by bench.py for the roofline object).
+struct ProfScope {
+  int slot;
+  hipStream_t stream;
+  ProfScope(const char *name, hipStream_t s);
+  ~ProfScope();
+};
+#define D4GS_LAUNCH(name, kernel, grid, block, lds, stream, ...)            \
+  do {                                                                        \
+    ProfScope _ps(name, stream);                                              \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+  } while (0)

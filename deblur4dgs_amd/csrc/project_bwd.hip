@@ -478,12 +478,12 @@ int d4gs_project_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
     attr_set = true;
   }
   const int blocks = (dims->N + BLK - 1) / BLK;
-  hipLaunchKernelGGL(k_project_bwd, dim3(blocks), dim3(BLK), lds, stream, a);
+  D4GS_LAUNCH("k_project_bwd", k_project_bwd, dim3(blocks), dim3(BLK), lds, stream, a);
   int rc = d4gs_check_launch("k_project_bwd");
   if (rc) return rc;
   float *red = grads->partials + (size_t)blocks * a.n_shared;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((a.n_shared + 255) / 256), dim3(256), 0, stream, grads->partials, blocks,
+  D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256), dim3(256), 0, stream, grads->partials, blocks,
                      a.n_shared, red);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, stream, a, (const float *)red);
+  D4GS_LAUNCH("k_finish", k_finish, dim3(1), dim3(256), 0, stream, a, (const float *)red);
   return d4gs_check_launch("k_finish");
 }

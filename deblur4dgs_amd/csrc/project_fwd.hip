@@ -266,17 +266,17 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
     return D4GS_EINVAL;
   }
   const int blocks = (dims->N + D4GS_PROJ_BLOCK - 1) / D4GS_PROJ_BLOCK;
-  hipLaunchKernelGGL(k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
+  D4GS_LAUNCH("k_project_fwd", k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
   int rc = d4gs_check_launch("k_project_fwd");
   if (rc) return rc;
   const int sblocks = (int)((n_inst + SCAN_TILE - 1) / SCAN_TILE);
-  hipLaunchKernelGGL(k_scan_sums, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, n_inst,
+  D4GS_LAUNCH("k_scan_sums", k_scan_sums, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, n_inst,
                      out->scan_ws);
-  hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, out->scan_ws, out->scan_ws, (int64_t)sblocks, 0,
+  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->scan_ws, out->scan_ws, (int64_t)sblocks, 0,
                      out->n_isect);
-  hipLaunchKernelGGL(k_scan_apply, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, out->scan_ws,
+  D4GS_LAUNCH("k_scan_apply", k_scan_apply, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, out->scan_ws,
                      n_inst, out->isect_offsets);
-  hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, out->tile_counts, out->tile_offsets, n_tiles, 1,
+  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->tile_counts, out->tile_offsets, n_tiles, 1,
                      (int64_t *)nullptr);
   return d4gs_check_launch("scan");
 }

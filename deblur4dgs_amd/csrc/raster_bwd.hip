@@ -260,11 +260,11 @@ int launch_bwd(const RasterBwdArgs &a, const GatherArgs &ga, int64_t n_isect, hi
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
   if (n_isect > 0) {
-    hipLaunchKernelGGL((k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+    D4GS_LAUNCH("k_raster_bwd", (k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
     int rc = d4gs_check_launch("k_raster_bwd");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL((k_gather<D, DEPTH>), dim3((ga.N + 255) / 256), dim3(256), 0, stream, ga);
+  D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH>), dim3((ga.N + 255) / 256), dim3(256), 0, stream, ga);
   return d4gs_check_launch("k_gather");
 }
 

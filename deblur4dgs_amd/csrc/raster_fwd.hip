@@ -132,7 +132,7 @@ template <int D, bool DEPTH>
 int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_raster_fwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+  D4GS_LAUNCH("k_raster_fwd", (k_raster_fwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
   return d4gs_check_launch("k_raster_fwd");
 }
 

@@ -134,6 +134,10 @@ typedef struct D4gsLeafGrads {
 } D4gsLeafGrads;
 
 int d4gs_version(void);
+/* optional per-kernel HIP-event timing (bench.py's roofline object): enable, run, then collect
+ * "kernel_name launches total_ms" lines.  Off by default; when off no events are created. */
+void d4gs_profile_enable(int on);
+int d4gs_profile_collect(char *buf /* [host] */, size_t cap);
 const char *d4gs_last_error(void);
 size_t d4gs_scan_ws_elems(int64_t n_instances);
 size_t d4gs_bwd_partials_elems(const D4gsDims *dims);
