@@ -29,7 +29,7 @@ class ProjIn(C.Structure):
 
 
 class ProjOut(C.Structure):
-    _fields_ = [(n, F) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tiles_touched",
+    _fields_ = [(n, F) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects", "tiles_touched",
                                  "isect_offsets", "tile_counts", "tile_offsets", "n_isect", "scan_ws")]
 
 
@@ -51,7 +51,7 @@ class LeafGrads(C.Structure):
                                  "v_rots", "v_transls", "v_times", "v_RTs", "v_viewmat", "partials")]
 
 
-RAW_PARAMS, RAW_COLORS = 1, 2
+RAW_PARAMS, RAW_COLORS, EXACT_CULL = 1, 2, 4
 DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
 TILE = 16
 GEOM_STRIDE = 8

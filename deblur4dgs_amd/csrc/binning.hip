@@ -16,7 +16,7 @@ namespace {
 struct EmitArgs {
   D4gsDims d;
   const float *geom;
-  const int32_t *radii;
+  const int32_t *tile_rects;
   const int32_t *tiles_touched;
   const int32_t *isect_offsets;
   int32_t *tile_cursor;  // tile_counts, counted down to 0
@@ -34,8 +34,8 @@ __global__ void __launch_bounds__(256) k_emit(const EmitArgs a) {
   if (cnt == 0) return;
   const int s = (int)(i / a.d.N), g = (int)(i - (int64_t)s * a.d.N);
   const float4 g0 = *reinterpret_cast<const float4 *>(a.geom + i * D4GS_GEOM_STRIDE);
-  int x0, y0, x1, y1;
-  tile_rect(g0.x, g0.y, a.radii[i], a.tw, a.th, x0, y0, x1, y1);
+  const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
+  const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
   const uint64_t hi = (uint64_t)__float_as_uint(g0.w) << 32;
   uint32_t e = (uint32_t)a.isect_offsets[i];
   const int tbase = s * a.tw * a.th;
@@ -119,7 +119,7 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   EmitArgs e;
   e.d = *dims;
   e.geom = proj->geom;
-  e.radii = proj->radii;
+  e.tile_rects = proj->tile_rects;
   e.tiles_touched = proj->tiles_touched;
   e.isect_offsets = proj->isect_offsets;
   e.tile_cursor = proj->tile_counts;

@@ -88,6 +88,28 @@ __device__ __forceinline__ void tile_rect(float mx, float my, int radius, int tw
   y1 = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)th);
 }
 
+// D4GS_EXACT_CULL: shrink the gsplat tile rectangle to the tiles that contain a pixel centre inside the ellipse
+// sigma <= tau, tau = ln(255*opacity) (alpha = opacity*exp(-sigma) >= 1/255).  Half-extents of that ellipse are
+// sqrt(2 tau Sigma_xx), sqrt(2 tau Sigma_yy) with Sigma the blurred 2-D covariance.  tau carries a 1% + 0.02 margin
+// and the extents 1e-3 px so fp32 rounding of sigma / exp in the rasterizer can never admit a pixel outside it.
+__device__ __forceinline__ void tight_rect(float mx, float my, float opac, float cov_xx, float cov_yy, int &x0, int &y0,
+                                           int &x1, int &y1) {
+  const float tau = __logf(255.f * opac) * 1.01f + 0.02f;
+  if (!(tau > 0.f)) {
+    x1 = x0, y1 = y0;
+    return;
+  }
+  const float ex = sqrtf(2.f * tau * cov_xx) + 1e-3f, ey = sqrtf(2.f * tau * cov_yy) + 1e-3f;
+  const float inv = 1.0f / D4GS_TILE;
+  // pixel j has centre j + 0.5; pixels with |mx - (j+0.5)| <= ex
+  const float jx0 = ceilf(mx - ex - 0.5f), jx1 = floorf(mx + ex - 0.5f);
+  const float jy0 = ceilf(my - ey - 0.5f), jy1 = floorf(my + ey - 0.5f);
+  const int tx0 = (int)fmaxf(floorf(jx0 * inv), (float)x0), tx1 = (int)fminf(floorf(jx1 * inv) + 1.f, (float)x1);
+  const int ty0 = (int)fmaxf(floorf(jy0 * inv), (float)y0), ty1 = (int)fminf(floorf(jy1 * inv) + 1.f, (float)y1);
+  x0 = tx0, x1 = max(tx1, tx0), y0 = ty0, y1 = max(ty1, ty0);
+  if (x1 == x0 || y1 == y0) x1 = x0, y1 = y0;
+}
+
 // camera constants, uniform across the grid (passed by value as a kernel argument -> SGPRs)
 struct Cam {
   float R[9];  // world->camera rotation

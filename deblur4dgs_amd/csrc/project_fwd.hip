@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
     float m2x = 0.f, m2y = 0.f, dep = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
     int cnt = 0;
+    int2 rect = make_int2(0, 0);
     if (p.radius > 0) {
       float idet = 1.f / p.det;
       ca = p.c * idet, cb = -p.b * idet, cc = p.a * idet;
@@ -142,6 +143,8 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       g1 = make_float4(ca, cb, cc, 0.f);
       int x0, y0, x1, y1;
       tile_rect(m2x, m2y, p.radius, a.tw, a.th, x0, y0, x1, y1);
+      if (d.flags & D4GS_EXACT_CULL) tight_rect(m2x, m2y, opac, p.a, p.c, x0, y0, x1, y1);
+      rect = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       cnt = (x1 - x0) * (y1 - y0);
       int *tc = a.out.tile_counts + (size_t)s * a.tw * a.th;
       for (int ty = y0; ty < y1; ty++)
@@ -154,6 +157,7 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
     a.out.conics[i * 3 + 1] = cb;
     a.out.conics[i * 3 + 2] = cc;
     a.out.tiles_touched[i] = cnt;
+    *reinterpret_cast<int2 *>(a.out.tile_rects + i * 2) = rect;
     float4 *gp = reinterpret_cast<float4 *>(a.out.geom + i * D4GS_GEOM_STRIDE);
     gp[0] = g0;
     gp[1] = g1;

@@ -39,6 +39,7 @@ class RenderCfg:
     far_plane: float = 1e10
     eps2d: float = 0.3
     radius_clip: float = 0.0
+    exact_cull: bool = True
 
     @property
     def DP(self) -> int:
@@ -54,7 +55,7 @@ class RenderCfg:
 
     def dims(self) -> L.Dims:
         return L.Dims(self.N, self.G, self.K, self.T, self.S, self.D, self.width, self.height, self.depth_mode,
-                      self.flags, self.n_sigmoid, self.near_plane, self.far_plane, self.eps2d, self.radius_clip)
+                      self.flags | (L.EXACT_CULL if self.exact_cull else 0), self.n_sigmoid, self.near_plane, self.far_plane, self.eps2d, self.radius_clip)
 
 
 @dataclass
@@ -106,7 +107,8 @@ class ProjectFn(torch.autograd.Function):
         st.proj_out = dict(
             means2d=torch.empty(S, N, 2, **f32), depths=torch.empty(S, N, **f32), conics=torch.empty(S, N, 3, **f32),
             radii=torch.empty(S, N, **i32), opac_act=torch.empty(N, **f32), ctab=torch.empty(N, cfg.DP, **f32),
-            geom=torch.empty(S * N, L.GEOM_STRIDE, **f32), tiles_touched=torch.empty(S * N, **i32),
+            geom=torch.empty(S * N, L.GEOM_STRIDE, **f32), tile_rects=torch.empty(S * N, 2, **i32),
+            tiles_touched=torch.empty(S * N, **i32),
             isect_offsets=torch.empty(S * N, **i32), tile_counts=torch.empty(S * tw * th, **i32),
             tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(1, dtype=torch.int64, device=dev),
             scan_ws=torch.empty(lib.d4gs_scan_ws_elems(S * N), **i32),

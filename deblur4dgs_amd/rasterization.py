@@ -53,6 +53,7 @@ def rasterization(
     absgrad: bool = False,
     rasterize_mode: str = "classic",
     channel_chunk: int = 32,
+    exact_cull: bool = True,
     **_ignored,
 ):
     if viewmats.shape[0] != 1 or Ks.shape[0] != 1:
@@ -68,7 +69,7 @@ def rasterization(
     colors_p, bg_p, D = _pad_channels(colors, bg)
     cfg = RenderCfg(N=N, G=0, K=0, T=0, S=1, D=colors_p.shape[-1], width=width, height=height,
                     depth_mode=_MODES[render_mode], flags=0, near_plane=near_plane, far_plane=far_plane, eps2d=eps2d,
-                    radius_clip=radius_clip)
+                    radius_clip=radius_clip, exact_cull=exact_cull)
     rc, ra, means2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors_p, None, None, None,
                                                   None, None, viewmats[0], Ks[0], bg_p)
     if colors_p.shape[-1] != D:  # drop the padding channels (keep the depth channel if any)

@@ -42,7 +42,11 @@ enum {
 enum { /* D4gsDims.flags */
   D4GS_RAW_PARAMS = 1,  /* quats/scales/opacities/motion_coefs are raw leaves: apply normalize/exp/sigmoid/softmax
                            (params.py:39-43).  When clear, scales/opacities are used as given (gsplat seam). */
-  D4GS_RAW_COLORS = 2   /* the first `n_sigmoid` colour channels are raw: apply sigmoid (params.py:40) */
+  D4GS_RAW_COLORS = 2,  /* the first `n_sigmoid` colour channels are raw: apply sigmoid (params.py:40) */
+  D4GS_EXACT_CULL = 4   /* bin a splat only into tiles that hold a pixel with alpha >= 1/255 (tight ellipse
+                           sigma <= ln(255*opacity), intersected with gsplat's 3-sigma tile rectangle).  Pixels in
+                           the dropped tiles would fail gsplat's alpha test anyway, so images and gradients are
+                           unchanged; only the intersection lists (tiles_touched / flatten ids) get shorter. */
 };
 
 enum { D4GS_DEPTH_NONE = 0, D4GS_DEPTH_ED = 1, D4GS_DEPTH_D = 2 }; /* render_mode RGB / RGB+ED / RGB+D */
@@ -86,6 +90,7 @@ typedef struct D4gsProjOut {
   float *opac_act;         /* [N]    activated opacity */
   float *ctab;             /* [N,DP] activated colour table, DP = 4*ceil(D/4) */
   float *geom;             /* [S*N,8] packed raster record */
+  int32_t *tile_rects;     /* [S*N,2] packed tile rectangle: x0 | x1<<16 , y0 | y1<<16 (min incl., max excl.) */
   int32_t *tiles_touched;  /* [S*N] */
   int32_t *isect_offsets;  /* [S*N] exclusive scan of tiles_touched */
   int32_t *tile_counts;    /* [S*tiles] splats per tile (consumed as cursors by d4gs_bin_sort) */

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _run_gpu(inp, W, H, mode, bg, requires_grad=False):
+def _run_gpu(inp, W, H, mode, bg, requires_grad=False, exact_cull=True):
     from deblur4dgs_amd.rasterization import rasterization
 
     dev = torch.device("cuda:0")
@@ -24,7 +24,7 @@ def _run_gpu(inp, W, H, mode, bg, requires_grad=False):
             t[k].requires_grad_()
     rc, ra, info = rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"][None],
                                  t["K"][None], W, H, backgrounds=None if bg is None else bg.to(dev)[None].float(),
-                                 render_mode=mode)
+                                 render_mode=mode, exact_cull=exact_cull)
     return rc, ra, info, t
 
 
@@ -37,7 +37,7 @@ def test_forward_matches_oracle(mode, D, N, W, H):
     ref_c, ref_a, ref_info = raster.rasterization(inp["means"], inp["quats"], inp["scales"], inp["opac"],
                                                   inp["colors"], inp["V"], inp["K"], W, H, background=bg,
                                                   render_mode=mode)
-    rc, ra, info, _ = _run_gpu(inp, W, H, mode, bg)
+    rc, ra, info, _ = _run_gpu(inp, W, H, mode, bg, exact_cull=False)  # gsplat's own tile lists
     torch.cuda.synchronize()
     assert rc.shape == (1, H, W, D + (mode != "RGB")) and ra.shape == (1, H, W, 1)
     # per-instance stage
@@ -60,7 +60,7 @@ def test_sorted_ids_match_oracle_order():
     # fp32 oracle so depth keys are bit-identical when the projection agrees
     ref_c, ref_a, ref_info = raster.rasterization(inp["means"], inp["quats"], inp["scales"], inp["opac"],
                                                   inp["colors"], inp["V"], inp["K"], W, H)
-    rc, ra, info, _ = _run_gpu(inp, W, H, "RGB", None)
+    rc, ra, info, _ = _run_gpu(inp, W, H, "RGB", None, exact_cull=False)
     torch.cuda.synchronize()
     a = info["flatten_ids"].cpu().long()
     b = ref_info["flatten_ids"]
@@ -128,3 +128,27 @@ def test_backward_is_deterministic():
         grads.append([tg[k].grad.clone() for k in ("means", "quats", "scales", "opac", "colors", "V")])
     for a, b in zip(*grads):
         assert torch.equal(a, b)  # no float atomics anywhere -> bitwise reproducible
+
+
+@pytest.mark.parametrize("mode,D", [("RGB+ED", 3), ("RGB", 4), ("RGB+ED", 16)])
+def test_exact_cull_changes_nothing(mode, D):
+    """D4GS_EXACT_CULL drops (tile, splat) pairs in which no pixel can pass alpha >= 1/255: the image and every
+    gradient must be BITWISE identical with and without it, while the intersection count shrinks."""
+    W, H, N = 256, 160, 20000
+    inp = static_inputs(N, W, H, seed=77, dtype=torch.float32, D=D, scale_mul=2.0)
+    bg = torch.linspace(0.2, 0.8, D)
+    res = []
+    for cull in (False, True):
+        rc, ra, info, tg = _run_gpu(inp, W, H, mode, bg, requires_grad=True, exact_cull=cull)
+        info["means2d"].retain_grad()
+        g = torch.Generator().manual_seed(3)
+        w = torch.randn(rc.shape, generator=g).to(rc.device)
+        ((rc * w).sum() + ra.sum()).backward()
+        torch.cuda.synchronize()
+        res.append((rc.detach().clone(), ra.detach().clone(), info["n_isect"], info["means2d"].grad.clone(),
+                    [tg[k].grad.clone() for k in ("means", "quats", "scales", "opac", "colors", "V")]))
+    (c0, a0, n0, m0, g0), (c1, a1, n1, m1, g1) = res
+    assert n1 < 0.9 * n0
+    assert torch.equal(c0, c1) and torch.equal(a0, a1) and torch.equal(m0, m1)
+    for x, y in zip(g0, g1):
+        assert torch.equal(x, y)
