@@ -377,13 +377,17 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
   }
 }
 
-// sum the per-block partial vectors in block order (deterministic): out[o] = sum_b partials[b][o]
+// sum the per-block partial vectors (deterministic): one workgroup per 4 outputs, 64 lanes stride the blocks,
+// fixed-shape tree over the 64 partial sums.
 __global__ void __launch_bounds__(256) k_reduce_partials(const float *partials, int n_blocks, int n, float *out) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n) return;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   float acc = 0.f;
-  for (int b = 0; b < n_blocks; b++) acc += partials[(size_t)b * n + o];
-  out[o] = acc;
+  if (o < n)
+    for (int b = lane; b < n_blocks; b += 64) acc += partials[(size_t)b * n + o];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (o < n && lane == 0) out[o] = acc;
 }
 
 // scatter the reduced shared gradients: v_Bs -> rots / transls / times ; camera deltas ; viewmat.  One block.
@@ -482,7 +486,7 @@ int d4gs_project_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   int rc = d4gs_check_launch("k_project_bwd");
   if (rc) return rc;
   float *red = grads->partials + (size_t)blocks * a.n_shared;
-  D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256), dim3(256), 0, stream, grads->partials, blocks,
+  D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 3) / 4), dim3(256), 0, stream, grads->partials, blocks,
                      a.n_shared, red);
   D4GS_LAUNCH("k_finish", k_finish, dim3(1), dim3(256), 0, stream, a, (const float *)red);
   return d4gs_check_launch("k_finish");

@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
   hi = min(wave_max_i(hi), end - 1);
   const size_t inst_base = (size_t)s * a.N;
 
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   for (int bh = hi; bh >= start; bh -= 64) {
     __syncthreads();
     const int idx = bh - lane;
@@ -116,8 +117,10 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
       const int gid = a.sorted_gid[idx];
       emit = a.sorted_emit[idx];
       const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
-      sg0[lane] = gp[0];
-      sg1[lane] = gp[1];
+      const float4 q0 = gp[0], q1 = gp[1];
+      sg0[lane] = q0;
+      // conic pre-scaled by log2(e) (exp2 argument) and 1/opacity for the opacity adjoint
+      sg1[lane] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, __builtin_amdgcn_rcpf(q0.z));
       const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
 #pragma unroll
       for (int v = 0; v < DV; v++) scol[lane * DV + v] = cp[v];
@@ -129,17 +132,18 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
     for (int j = 0; j < nb; j++) {
       const int cur = bh - j;
       const float4 g0 = sg0[j], g1 = sg1[j];
-      float dx[4], dy[4], vis[4], alpha[4];
+      float dx[4], dy[4], ov[4], am[4];
       bool valid[4];
       bool any = false;
 #pragma unroll
       for (int p = 0; p < 4; p++) {
         dx[p] = g0.x - pxf[p];
         dy[p] = g0.y - pyf[p];
-        const float sigma = 0.5f * (g1.x * dx[p] * dx[p] + g1.z * dy[p] * dy[p]) + g1.y * dx[p] * dy[p];
-        vis[p] = __expf(-sigma);
-        alpha[p] = fminf(0.999f, g0.z * vis[p]);
-        valid[p] = (cur <= last[p]) && (sigma >= 0.f) && (alpha[p] >= (1.f / 255.f));
+        const float sig2 = 0.5f * (g1.x * dx[p] * dx[p] + g1.z * dy[p] * dy[p]) + g1.y * dx[p] * dy[p];  // sigma*log2e
+        ov[p] = g0.z * __builtin_amdgcn_exp2f(-sig2);
+        const float alpha = fminf(0.999f, ov[p]);
+        valid[p] = (cur <= last[p]) && (sig2 >= 0.f) && (alpha >= (1.f / 255.f));
+        am[p] = valid[p] ? alpha : 0.f;
         any = any || valid[p];
       }
       if (!__any(any)) continue;
@@ -153,47 +157,46 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
         if (v * 4 + 3 < D) col[v * 4 + 3] = c4.w;
       }
       if (DEPTH) col[D] = g0.w;
-      float gx = 0.f, gy = 0.f, ga = 0.f, gb = 0.f, gc = 0.f, go = 0.f, gcol[NCH];
+      // row = [gx, gy, ga, gb, gc, go, gcol...]; branch-free: an invalid pixel has am = 0 -> ra = 1, fac = 0
+      float row[R];
 #pragma unroll
-      for (int c = 0; c < NCH; c++) gcol[c] = 0.f;
+      for (int r = 0; r < R; r++) row[r] = 0.f;
+      float ra[4], fac[4], v_alpha[4];
 #pragma unroll
       for (int p = 0; p < 4; p++) {
-        if (valid[p]) {
-          const float ra = 1.f / (1.f - alpha[p]);
-          T[p] *= ra;
-          const float fac = alpha[p] * T[p];
-          float v_alpha = 0.f;
+        ra[p] = __builtin_amdgcn_rcpf(1.f - am[p]);
+        T[p] *= ra[p];
+        fac[p] = am[p] * T[p];
+        v_alpha[p] = va[p] * ra[p];
+      }
 #pragma unroll
-          for (int c = 0; c < NCH; c++) {
-            gcol[c] += fac * vo[p][c];
-            v_alpha += (col[c] * T[p] - buf[p][c] * ra) * vo[p][c];
-            buf[p][c] += col[c] * fac;
-          }
-          v_alpha += va[p] * ra;
-          if (g0.z * vis[p] <= 0.999f) {
-            const float v_sigma = -g0.z * vis[p] * v_alpha;
-            ga += 0.5f * v_sigma * dx[p] * dx[p];
-            gb += v_sigma * dx[p] * dy[p];
-            gc += 0.5f * v_sigma * dy[p] * dy[p];
-            gx += v_sigma * (g1.x * dx[p] + g1.y * dy[p]);
-            gy += v_sigma * (g1.y * dx[p] + g1.z * dy[p]);
-            go += vis[p] * v_alpha;
-          }
+      for (int c = 0; c < NCH; c++) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          row[6 + c] += fac[p] * vo[p][c];
+          v_alpha[p] += (col[c] * T[p] - buf[p][c] * ra[p]) * vo[p][c];
+          buf[p][c] += col[c] * fac[p];
         }
       }
-      gx = wave_sum_to_lane63(gx);
-      gy = wave_sum_to_lane63(gy);
-      ga = wave_sum_to_lane63(ga);
-      gb = wave_sum_to_lane63(gb);
-      gc = wave_sum_to_lane63(gc);
-      go = wave_sum_to_lane63(go);
 #pragma unroll
-      for (int c = 0; c < NCH; c++) gcol[c] = wave_sum_to_lane63(gcol[c]);
+      for (int p = 0; p < 4; p++) {
+        const bool ok = valid[p] && (ov[p] <= 0.999f);
+        const float vs = ok ? -ov[p] * v_alpha[p] : 0.f;  // dL/dsigma
+        const float vsx = vs * dx[p], vsy = vs * dy[p];
+        row[2] += vsx * dx[p];              // 2 * dL/da
+        row[3] += vsx * dy[p];              // dL/db
+        row[4] += vsy * dy[p];              // 2 * dL/dc
+        row[0] += g1.x * vsx + g1.y * vsy;  // log2e * dL/dx
+        row[1] += g1.y * vsx + g1.z * vsy;  // log2e * dL/dy
+        row[5] -= vs;                       // opacity * dL/dopacity
+      }
+      wave_sum_array_lane63(row);
       if (lane == 63) {
-        float *row = sgrad + j * RP;
-        row[0] = gx, row[1] = gy, row[2] = ga, row[3] = gb, row[4] = gc, row[5] = go;
+        float *dst = sgrad + j * RP;
+        dst[0] = row[0] * LN2, dst[1] = row[1] * LN2, dst[2] = 0.5f * row[2], dst[3] = row[3], dst[4] = 0.5f * row[4];
+        dst[5] = row[5] * g1.w;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) row[6 + c] = gcol[c];
+        for (int c = 0; c < NCH; c++) dst[6 + c] = row[6 + c];
       }
     }
     __syncthreads();

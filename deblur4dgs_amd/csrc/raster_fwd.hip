@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
 
   const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   const size_t inst_base = (size_t)s * a.N;
+  constexpr float LOG2E = 1.4426950408889634f;
   for (int b = start; b < end; b += 64) {
     if (__all(done[0] && done[1] && done[2] && done[3])) break;
     __syncthreads();
@@ -75,8 +76,9 @@ __global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
     if (idx < end) {
       const int gid = a.sorted_gid[idx];
       const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
+      const float4 q1 = gp[1];
       sg0[lane] = gp[0];
-      sg1[lane] = gp[1];
+      sg1[lane] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, 0.f);  // exp2 argument (same as the bwd)
       const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
 #pragma unroll
       for (int v = 0; v < DV; v++) scol[lane * DV + v] = cp[v];
@@ -95,8 +97,8 @@ __global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
 #pragma unroll
       for (int p = 0; p < 4; p++) {
         const float dx = g0.x - pxf[p], dy = g0.y - pyf[p];
-        const float sigma = 0.5f * (g1.x * dx * dx + g1.z * dy * dy) + g1.y * dx * dy;
-        const float alpha = fminf(0.999f, g0.z * __expf(-sigma));
+        const float sigma = 0.5f * (g1.x * dx * dx + g1.z * dy * dy) + g1.y * dx * dy;  // sigma * log2(e)
+        const float alpha = fminf(0.999f, g0.z * __builtin_amdgcn_exp2f(-sigma));
         bool valid = !done[p] && (sigma >= 0.f) && (alpha >= (1.f / 255.f));
         const float nT = T[p] * (1.f - alpha);
         const bool stop = valid && (nT <= 1e-4f);
