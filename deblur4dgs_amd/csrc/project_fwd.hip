@@ -98,8 +98,11 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
   }
   if (dyn_block) __syncthreads();
 
-  for (int s = 0; s < S; s++) {
+  // each wave walks the sub-samples from a different start, so resident waves hit all S*tiles counters at once
+  const int rot = (blockIdx.x * (D4GS_PROJ_BLOCK / 64) + (tid >> 6)) % S;
+  for (int it = 0; it < S; it++) {
     if (!active) continue;
+    const int s = (it + rot) % S;
     float mw[3], Rm[9];
     if (g < G) {
       float v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
