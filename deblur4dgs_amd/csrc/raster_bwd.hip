@@ -23,6 +23,7 @@ struct RasterBwdArgs {
   const float *background;
   const int32_t *tile_offsets;
   const int32_t *sorted_gid;
+  const int32_t *tile_order;
   const int32_t *sorted_emit;
   const float *out;     // forward render_colors (needed to undo the ED division)
   const float *alphas;
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
   constexpr int DP = (D + 3) & ~3;
   constexpr int DV = DP / 4;
   constexpr int R = 6 + NCH;
-  constexpr int RP = R | 1;  // odd LDS row stride
+  constexpr int RP = (R + 1) | 1;  // odd LDS row stride with >= 1 pad slot (wave_sum_store's dump slot)
   __shared__ float4 sg0[64];
   __shared__ float4 sg1[64];
   __shared__ float4 scol[64 * DV];
@@ -57,7 +58,8 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
 
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
-  const int t = xcd_remap_b(blockIdx.x, n_tiles);
+  const int t = a.tile_order ? (blockIdx.x < n_tiles ? a.tile_order[blockIdx.x] : n_tiles)
+                             : xcd_remap_b(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   if (end <= start) return;
@@ -190,14 +192,8 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
         row[1] += g1.y * vsx + g1.z * vsy;  // log2e * dL/dy
         row[5] -= vs;                       // opacity * dL/dopacity
       }
-      wave_sum_array_lane63(row);
-      if (lane == 63) {
-        float *dst = sgrad + j * RP;
-        dst[0] = row[0] * LN2, dst[1] = row[1] * LN2, dst[2] = 0.5f * row[2], dst[3] = row[3], dst[4] = 0.5f * row[4];
-        dst[5] = row[5] * g1.w;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) dst[6 + c] = row[6 + c];
-      }
+      row[0] *= LN2, row[1] *= LN2, row[2] *= 0.5f, row[4] *= 0.5f, row[5] *= g1.w;
+      wave_sum_store(row, sgrad + j * RP, lane);
     }
     __syncthreads();
     if (emit >= 0) {
@@ -281,7 +277,7 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   a.ed = dims->depth_mode == D4GS_DEPTH_ED;
   a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
-  a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.sorted_emit = isect->sorted_emit;
+  a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.sorted_emit = isect->sorted_emit, a.tile_order = isect->tile_order;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids;
   a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad;
   GatherArgs ga;
