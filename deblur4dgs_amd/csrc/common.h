@@ -17,6 +17,8 @@ struct float9 {
   float m[9];
 };
 
+// clamp to [0,1]; lowers to the free `clamp` output modifier of the producing VALU op
+__device__ __forceinline__ float sat01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // 3x3 row-major helpers -----------------------------------------------------------------------

@@ -95,7 +95,7 @@ class FlatGradAllReduce:
         self.group = group
         n = sum(leaves[k].numel() for k in self.names)
         ref = leaves[self.names[0]]
-        self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.views, off = {}, 0
         for k in self.names:
             m = leaves[k].numel()

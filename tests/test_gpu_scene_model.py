@@ -1,0 +1,112 @@
+"""GPU parity (seam S2): `SceneModel.render` - same signature / output dict / side channels as the reference's
+flow3d/scene_model.py:162-487 - against the oracle's restatement of that method (oracle/scene.py) driven by the
+oracle's restatement of the host-side generator (oracle/camera.py) with the same MoveModel weights."""
+import pytest
+import torch
+
+from deblur4dgs_amd.synth import make_scene
+from oracle import camera as ocam
+from oracle import scene as oscene
+from tests.util import frac_bad, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(N, G, K, W, H, seed, dev):
+    from deblur4dgs_amd.scene_model import GaussianParams, MotionBases, SceneModel
+
+    sc = make_scene(N, G, K, 1, W, H, seed=seed, dtype=torch.float32, T=8)
+    sc["scales"] = sc["scales"] + 1.3
+    keys = ("means", "quats", "scales", "colors", "opacities")
+    fg = GaussianParams(*[sc[k][:G].clone() for k in keys], motion_coefs=sc["motion_coefs"].clone())
+    bg = GaussianParams(*[sc[k][G:].clone() for k in keys])
+    mb = MotionBases(sc["rots"].clone(), sc["transls"].clone())
+    model = SceneModel(sc["K"][None].clone(), sc["viewmat"][None].clone(), fg, mb, bg).to(dev)
+    torch.manual_seed(seed)
+    with torch.no_grad():  # non-trivial camera deltas and exposure half-widths
+        for head in (model.move_model.RT_head0, model.move_model.RT_head1):
+            head[-1].bias.copy_(0.004 * torch.randn(6))
+        model.move_model.time_params.copy_(torch.tensor([[0.5, 0.3, 0.45, 0.6, 0.2, 0.5, 0.7, 0.5]]))
+    return model, sc
+
+
+def _oracle(model, sc, t, W, H, mode, stage, return_depth, return_mask, target_ts, target_w2cs):
+    G = model.num_fg_gaussians
+    dd = lambda x: x.detach().double().cpu().clone().requires_grad_()
+    fg = {k: dd(v) for k, v in model.fg.params.items()}
+    bg = {k: dd(v) for k, v in model.bg.params.items()}
+    bases = {k: dd(v) for k, v in model.motion_bases.params.items()}
+    sd = {k: v.detach().cpu() for k, v in model.move_model.state_dict().items()}
+    w2c = sc["viewmat"].double()
+    RTs, times, dT = ocam.forward_start_end_mid(sd, w2c[:3, :3].float(), w2c[:3, 3:4].float(), t, 11, stage)
+    sel = {"mid": slice(5, 6), "start": slice(0, 1), "end": slice(10, 11)}.get(mode, slice(None))
+    out = oscene.render_exposure(fg, bg, bases, times[0, sel].double(), RTs[sel].double(), w2c, sc["K"].double(), (W, H),
+                                 bg_color=1.0, return_depth=return_depth, return_mask=return_mask,
+                                 target_ts=target_ts, target_w2cs=target_w2cs, single=mode in ("mid", "start", "end"))
+    return out, (fg, bg, bases), dT
+
+
+@pytest.mark.parametrize("mode,stage,t,tracks", [("blury", "second", 3.0, True), ("mid", "second", 2.0, False),
+                                                 ("blury", "first", 3.0, False)])
+def test_render_matches_oracle(mode, stage, t, tracks):
+    dev = torch.device("cuda:0")
+    N, G, K, W, H = 900, 500, 4, 64, 48
+    model, sc = _build(N, G, K, W, H, 17, dev)
+    tt = torch.tensor([1.0, 2.5, 4.0, 6.0]) if tracks else None
+    tw = None
+    if tracks:
+        from deblur4dgs_amd.move_model import se3_to_SE3
+
+        tw = torch.cat([se3_to_SE3(0.01 * torch.randn(4, 6)), torch.tensor([0, 0, 0, 1.0]).expand(4, 1, 4)], 1)
+    ref, (fg, bg, bases), dT = _oracle(model, sc, t, W, H, mode, stage, True, True, None if tt is None else tt.double(),
+                                       None if tw is None else tw.double())
+    out = model.render(t, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H),
+                       target_ts=None if tt is None else tt.to(dev), target_w2cs=None if tw is None else tw.to(dev),
+                       return_depth=True, return_mask=True, mode=mode, stage=stage)
+    torch.cuda.synchronize()
+    S = 1 if mode == "mid" else 11
+    assert out["img"].shape == (1, H, W, 3) and out["mask"].shape == (1, H, W, 1) and out["depth"].shape == (1, H, W, 1)
+    assert out["acc"].shape == (1, H, W, 1) and out["deltaT"].shape == (1, 1, 1) and out["RTs"].shape == (S, 3, 4)
+    Dp = 3 + 1 + (12 if tracks else 0) + 1
+    assert out["exposure_imgs"].shape == (S, 1, H, W, Dp)
+    if tracks:
+        assert out["tracks_3d"].shape == (1, H, W, 4, 3) and out["pred_sharp_img"].shape == (1, H, W, 3)
+    for k in ("img", "mask", "depth", "acc") + (("tracks_3d",) if tracks else ()):
+        assert frac_bad(out[k].cpu(), ref[k], 1e-4) < 3e-3, (k, rel_err(out[k].cpu(), ref[k]))
+    assert frac_bad(out["exposure_imgs"].cpu(), ref["exposure_imgs"], 1e-4) < 3e-3
+    assert abs(out["deltaT"].item() - dT.item()) < 1e-7
+    assert len(model._current_xys) == S and model._current_xys[0].shape == (1, N, 2)
+    assert model._current_radii[0].shape == (1, N) and model._current_radii[0].dtype == torch.int32
+
+    # backward: image loss + the side-channel contract (means2d.grad per sub-sample, trainer.py:975)
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(1, H, W, 3, generator=g)
+    wd = torch.randn(1, H, W, 1, generator=g)
+    (out["img"] * w.to(dev)).sum().add((out["depth"] * wd.to(dev)).sum()).backward()
+    ((ref["img"] * w.double()).sum() + (ref["depth"] * wd.double()).sum()).backward()
+    torch.cuda.synchronize()
+    for name, got_p, ref_p in (("fg.means", model.fg.params["means"], fg["means"]),
+                               ("bg.scales", model.bg.params["scales"], bg["scales"]),
+                               ("fg.motion_coefs", model.fg.params["motion_coefs"], fg["motion_coefs"]),
+                               ("rots", model.motion_bases.params["rots"], bases["rots"]),
+                               ("transls", model.motion_bases.params["transls"], bases["transls"])):
+        assert frac_bad(got_p.grad.cpu(), ref_p.grad, 2e-3) < 5e-3, (name, rel_err(got_p.grad.cpu(), ref_p.grad))
+    assert all(x.grad is not None and x.grad.shape == (1, N, 2) for x in model._current_xys)
+    assert model.move_model.time_params.grad is not None or stage == "first" or mode == "mid"
+    if mode == "blury":
+        assert model.move_model.RT_head0[-1].bias.grad.abs().sum() > 0  # camera deltas are trained through v_RTs
+
+
+def test_render_view_and_inference_mode():
+    from deblur4dgs_amd.scene_model import render_view
+
+    dev = torch.device("cuda:0")
+    model, sc = _build(600, 300, 3, 80, 48, 5, dev)
+    img = render_view(model, 2, torch.eye(4, device=dev), 1.2, (80, 48))
+    assert img.shape == (48, 80, 3) and img.dtype == torch.uint8
+    with torch.no_grad():
+        o = model.render(2, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (80, 48), bg_only=True)
+        assert o["img"].shape == (1, 48, 80, 3)
+        o = model.render(2, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (80, 48), fg_only=True, return_mask=True,
+                         filter_mask=torch.arange(300, device=dev) % 3 != 0)
+        assert o["mask"].shape == (1, 48, 80, 1)

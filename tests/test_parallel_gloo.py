@@ -1,0 +1,92 @@
+"""N>1 path on CPU: world_size-2 (and 3) `gloo` processes run the exposure-sharded blend + flat gradient
+all-reduce and must reproduce the single-process blend of the reference (oracle/scene.py:blend_exposure,
+which restates flow3d/scene_model.py:386-397 literally) - forward and backward."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, S, C, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deblur4dgs_amd.exposure import reference_policy
+    from deblur4dgs_amd.parallel import FlatGradAllReduce, ShardedBlendFn, owned_subsamples
+
+    g = torch.Generator().manual_seed(seed)
+    H, W = 6, 5
+    renders = torch.rand(S, H, W, C, generator=g, dtype=torch.float64)
+    renders[:, 0, 0, 3] = 0.0  # exact ties on the max-policy channel (e.g. mask == 0 everywhere)
+    renders[S - 1, 1, 1, 3] = 5.0  # the LAST sub-sample holds the max: the reference takes max{raw_0..S-2, mean}
+    alphas = torch.rand(S, H, W, generator=g, dtype=torch.float64)
+    wb = torch.randn(H, W, C, generator=g, dtype=torch.float64)
+    wa = torch.randn(H, W, generator=g, dtype=torch.float64)
+    scale = torch.ones(S, dtype=torch.float64, requires_grad=True)  # a "leaf" every sub-sample depends on
+    own = owned_subsamples(S, world, rank)
+    loc = (renders[own] * scale[own].view(-1, 1, 1, 1)).requires_grad_() if False else renders[own] * scale[own].view(-1, 1, 1, 1)
+    loc.retain_grad()
+    la = alphas[own].clone().requires_grad_()
+    out, acc = ShardedBlendFn.apply(loc, la, own, S, reference_policy(C), None)
+    ((out * wb).sum() + (acc * wa).sum()).backward()
+    leaves = {"scale": scale}
+    FlatGradAllReduce(leaves).reduce(leaves)
+    q.put((rank, own, out.detach(), acc.detach(), loc.grad.clone(), la.grad.clone(), scale.grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,S,C", [(2, 8, 17), (2, 5, 5), (3, 7, 4), (2, 1, 5), (2, 2, 17)])
+def test_sharded_blend_matches_reference_blend(world, S, C):
+    from oracle import scene as oscene
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, S, C, 11, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    g = torch.Generator().manual_seed(11)
+    H, W = 6, 5
+    renders = torch.rand(S, H, W, C, generator=g, dtype=torch.float64)
+    renders[:, 0, 0, 3] = 0.0
+    renders[S - 1, 1, 1, 3] = 5.0
+    alphas = torch.rand(S, H, W, generator=g, dtype=torch.float64)
+    wb = torch.randn(H, W, C, generator=g, dtype=torch.float64)
+    wa = torch.randn(H, W, generator=g, dtype=torch.float64)
+    scale = torch.ones(S, dtype=torch.float64, requires_grad=True)
+    r = (renders * scale.view(-1, 1, 1, 1))
+    r.retain_grad()
+    a = alphas.clone().requires_grad_()
+    blended, acc, _ = oscene.blend_exposure([r[s][None] for s in range(S)], [a[s][None] for s in range(S)], single=(S == 1))
+    ((blended[0] * wb).sum() + (acc[0] * wa).sum()).backward()
+    for rank, own, out, acc_r, gr, ga, gscale in res:
+        torch.testing.assert_close(out, blended[0].detach(), rtol=0, atol=1e-14)
+        torch.testing.assert_close(acc_r, acc[0].detach(), rtol=0, atol=1e-14)
+        torch.testing.assert_close(gr, r.grad[own], rtol=0, atol=1e-14)
+        torch.testing.assert_close(ga, a.grad[own], rtol=0, atol=1e-14)
+        torch.testing.assert_close(gscale, scale.grad, rtol=0, atol=1e-12)  # all-reduced leaf gradient
+
+
+def test_owned_subsamples_partition():
+    from deblur4dgs_amd.parallel import owned_subsamples
+
+    for S in (1, 8, 11, 16):
+        for world in (1, 2, 4, 8):
+            allv = sorted(s for r in range(world) for s in owned_subsamples(S, world, r))
+            assert allv == list(range(S))
