@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--shard", default="exposure", choices=["exposure", "views"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL code path with world_size 1")
     return ap.parse_args()
 
 
@@ -118,11 +119,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from deblur4dgs_amd import _lib as L
     from deblur4dgs_amd.exposure import render_exposure
@@ -134,7 +138,7 @@ def main():
     sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0)
     bg = torch.ones(3, device=dev)
     sharder = None
-    if world > 1:
+    if use_dist:
         sharder = ShardedExposure(world, rank, mode=args.shard)
 
     last = {}
@@ -154,7 +158,7 @@ def main():
         last["res"] = res
 
     def sync():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
 
             dist.barrier()
@@ -180,7 +184,7 @@ def main():
         for line in buf.value.decode().splitlines():
             nm, cnt, ms = line.split()
             kern[nm] = (int(cnt), float(ms))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -244,7 +248,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Gaussians/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         dist.destroy_process_group()
