@@ -8,11 +8,12 @@ opacities, colours, motion coefficients, bases, times, camera deltas, viewmat). 
 before the timed region.  value = Gaussians / t_frame (whole job); `instances_per_s` = N*S / t_frame.
 
 N GPUs (torchrun, one rank per GPU, RCCL):
-  --shard exposure (default): BASELINE config 4 - the S sub-samples of the SAME frame are split over the ranks,
-      the blended image is an all-reduce (SUM, + MAX/MIN channels), leaf gradients are all-reduced.  Total work is
-      fixed -> "scaling": "strong".
-  --shard views: every rank renders its own full S-sub-sample frame (data parallel over camera views), gradients
-      all-reduced.  Per-GPU work fixed -> "scaling": "weak".
+  --shard views (default): every rank renders its own full S-sub-sample frame (data parallel over camera views, the
+      unit a training step batches: flow3d/trainer.py:211-222 renders 3 independent groups per step), leaf gradients
+      all-reduced in one flat buffer.  Per-GPU work fixed -> "scaling": "weak"; value = world * N / t.
+  --shard exposure: BASELINE config 4 - the S sub-samples of the SAME frame are split over the ranks, the blended
+      image is an all-reduce (SUM, + MAX/MIN channels), leaf gradients are all-reduced.  Total work is fixed ->
+      "scaling": "strong" (latency-bound: one sub-sample is ~0.5 ms of GPU work against a 24 MB gradient all-reduce).
 """
 from __future__ import annotations
 
@@ -48,7 +49,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=list(CONFIGS))
-    ap.add_argument("--shard", default="exposure", choices=["exposure", "views"])
+    ap.add_argument("--shard", default="views", choices=["exposure", "views"])
+    ap.add_argument("--channels", type=int, default=3, choices=[3, 16],
+                    help="colour channels before depth: 3 = RGB+ED (headline), 16 = the reference's dynamic-training "
+                         "shape (rgb + mask + 4x3 track channels + depth = 17, scene_model.py:233-296)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL code path with world_size 1")
@@ -59,17 +63,17 @@ def to_dev(sc, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
 
 
-def make_inputs(name, dev, seed_offset=0):
+def make_inputs(name, dev, seed_offset=0, channels=3):
     from deblur4dgs_amd.synth import make_scene
 
     N, G, K, S, W, H = CONFIGS[name]
-    sc = make_scene(N, G, K, S, W, H, seed=SEEDS[name] + seed_offset)
+    sc = make_scene(N, G, K, S, W, H, seed=SEEDS[name] + seed_offset, D=channels)
     d = to_dev(sc, dev)
     leaves = {k: d[k].clone().requires_grad_() for k in
               ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls", "times", "RTs",
                "viewmat")}
     g = torch.Generator().manual_seed(7)
-    wimg = torch.randn(H, W, 4, generator=g).to(dev)
+    wimg = torch.randn(H, W, channels + 1, generator=g).to(dev)
     wacc = torch.randn(H, W, generator=g).to(dev)
     return sc, d, leaves, wimg, wacc
 
@@ -135,8 +139,8 @@ def main():
     name = args.config
     N, G, K, S, W, H = CONFIGS[name]
     views = world > 1 and args.shard == "views"
-    sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0)
-    bg = torch.ones(3, device=dev)
+    sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0, channels=args.channels)
+    bg = torch.ones(args.channels, device=dev)
     sharder = None
     if use_dist:
         sharder = ShardedExposure(world, rank, mode=args.shard)
@@ -200,7 +204,7 @@ def main():
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if views else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}: {N} Gaussians ({G} dynamic), {K} motion bases, {W}x{H}, N_exposure={S}, "
-                               f"RGB+ED (4 ch), fwd+bwd to all leaves", "gaussians": N, "exposure_subsamples": S,
+                                f"{args.channels}+depth channels, fwd+bwd to all leaves", "gaussians": N, "exposure_subsamples": S,
                    "parallelism": "1 GPU" if world == 1 else f"{args.shard}-sharded x{world} (RCCL)"},
         "instances_per_s": value * S,
     }
@@ -223,7 +227,7 @@ def main():
             cnts = (to[1:] - to[:-1])
             proc_bwd = torch.where(cnts > 0, (tmax - to[:-1] + 1).clamp(min=0), torch.zeros_like(cnts))
             pairs_bwd = float(proc_bwd.sum().item()) * 256.0
-            R = 6 + 4
+            R = 6 + args.channels + 1
             # algorithmic bytes of k_raster_bwd (DESIGN.md "roofline"): per intersection replayed: id 4 + emit 4 +
             # geom 32 + colours 16 read, gradient row R*4 written; per pixel: v_out 16 + v_alpha 4 + alpha 4 +
             # last_id 4 + out 16 read.

@@ -84,7 +84,7 @@ struct SortArgs {
   const int32_t *gid_of_emit;
   int32_t *sorted_gid;
   int32_t *sorted_emit;
-  int cap;
+  int lo, cap;  // this launch sorts the lists with lo < n <= cap in LDS; cap < 0: everything longer, in global memory
 };
 
 __global__ void __launch_bounds__(256) k_tile_sort(const SortArgs a) {
@@ -92,9 +92,9 @@ __global__ void __launch_bounds__(256) k_tile_sort(const SortArgs a) {
   const int t = blockIdx.x;
   const int base = a.tile_offsets[t];
   const int n = a.tile_offsets[t + 1] - base;
-  if (n <= 0) return;
+  if (n <= a.lo || (a.cap >= 0 && n > a.cap)) return;
   uint64_t *gk = a.keys + base;
-  if (n <= a.cap) {
+  if (a.cap >= 0) {
     for (int p = threadIdx.x; p < n; p += blockDim.x) skeys[p] = gk[p];
     __syncthreads();
     bitonic_sort(skeys, n);
@@ -138,16 +138,20 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   int rc = d4gs_check_launch("k_emit");
   if (rc) return rc;
   const int n_tiles = dims->S * e.tw * e.th;
-  // LDS budget: 4x the mean list length, clamped to [2048, 16384] keys (16..128 KB)
-  int64_t avg = isect->n_isect / n_tiles + 1;
-  int cap = 2048;
-  while (cap < 4 * avg && cap < 16384) cap <<= 1;
-  SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit, cap};
+  // Three size classes, one launch each (a workgroup exits at once if its list is not in the class): short lists
+  // sort with 16 KB of LDS (8+ workgroups / CU), long ones with up to 128 KB, anything longer in global memory.
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
     attr_set = true;
   }
-  D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(256), (size_t)cap * 8, stream, s);
+  const int classes[3][2] = {{0, 2048}, {2048, 16384}, {16384, -1}};
+  for (int c = 0; c < 3; c++) {
+    if (c > 0 && isect->n_isect <= classes[c][0]) break;  // no list can be that long
+    SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
+               classes[c][0], classes[c][1]};
+    const size_t lds = classes[c][1] > 0 ? (size_t)classes[c][1] * 8 : 0;
+    D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(256), lds, stream, s);
+  }
   return d4gs_check_launch("k_tile_sort");
 }

@@ -123,8 +123,11 @@ class ProjectFn(torch.autograd.Function):
         ctx.needs = [t is not None and t.requires_grad for t in
                      (means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat)]
         o = st.proj_out
-        ctx.mark_non_differentiable(o["radii"])
-        return o["means2d"], o["conics"], o["depths"], o["opac_act"], o["ctab"], o["radii"]
+        # return ALIASES of the buffers: autograd attaches grad_fn (-> ctx -> st) to the returned objects, and st must
+        # not hold those objects or every call leaks a reference cycle until the cyclic GC runs
+        outs = tuple(o[k].view(o[k].shape) for k in ("means2d", "conics", "depths", "opac_act", "ctab", "radii"))
+        ctx.mark_non_differentiable(outs[5])
+        return outs
 
     @staticmethod
     def backward(ctx, v_means2d, v_conics, v_depths, v_opac_act, v_ctab, _v_radii):
@@ -192,7 +195,7 @@ class RasterFn(torch.autograd.Function):
         L.check(lib.d4gs_raster_fwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), _stream()),
                 "d4gs_raster_fwd")
         ctx.st = st
-        return st.raster["render_colors"], st.raster["render_alphas"].unsqueeze(-1)
+        return st.raster["render_colors"].view(S, H, W, cfg.NCH), st.raster["render_alphas"].unsqueeze(-1)
 
     @staticmethod
     def backward(ctx, v_colors, v_alphas):

@@ -152,3 +152,32 @@ def test_exact_cull_changes_nothing(mode, D):
     assert torch.equal(c0, c1) and torch.equal(a0, a1) and torch.equal(m0, m1)
     for x, y in zip(g0, g1):
         assert torch.equal(x, y)
+
+
+def test_long_tile_lists_all_sort_paths():
+    """All Gaussians piled on a few tiles: exercises the 128-KB-LDS class (> 2048 per tile) and the global-memory
+    bitonic fallback (> 16384 per tile) of k_tile_sort; the per-tile order must be depth-sorted."""
+    from deblur4dgs_amd.rasterization import rasterization
+
+    dev = torch.device("cuda:0")
+    W, H, N = 64, 32, 40000
+    g = torch.Generator().manual_seed(1)
+    means = torch.zeros(N, 3)
+    means[:, 0] = (torch.rand(N, generator=g) - 0.5) * 0.2
+    means[: N // 2, 0] += 1.2  # half of them land in another tile column
+    means[:, 1] = (torch.rand(N, generator=g) - 0.5) * 0.1
+    means[:, 2] = 2.0 + 6.0 * torch.rand(N, generator=g)
+    K = torch.tensor([[64.0, 0, 32], [0, 64.0, 16], [0, 0, 1]])
+    rc, ra, info = rasterization(means.to(dev), torch.tensor([1.0, 0, 0, 0]).repeat(N, 1).to(dev),
+                                 torch.full((N, 3), 0.01).to(dev), torch.full((N,), 0.01).to(dev),
+                                 torch.rand(N, 3, generator=g).to(dev), torch.eye(4)[None].to(dev), K[None].to(dev), W, H,
+                                 exact_cull=False)
+    torch.cuda.synchronize()
+    offs = torch.cat([info["isect_offsets"].flatten().cpu().long(), torch.tensor([info["n_isect"]])])
+    counts = offs[1:] - offs[:-1]
+    assert counts.max() > 16384 and ((counts > 2048) & (counts <= 16384)).any()
+    depth = info["depths"][0].cpu()
+    ids = info["flatten_ids"].cpu().long()
+    for t in range(len(counts)):
+        d = depth[ids[offs[t]:offs[t + 1]]]
+        assert (d[1:] >= d[:-1]).all(), f"tile {t} not depth sorted ({counts[t]} splats)"
