@@ -201,7 +201,7 @@ def main():
     out = {
         "metric": "Gaussians/s fwd+bwd, 288x512, N_exposure=8" if name == "cfg2" else f"Gaussians/s fwd+bwd ({name})",
         "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if views else "strong",
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if args.shard == "views" else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}: {N} Gaussians ({G} dynamic), {K} motion bases, {W}x{H}, N_exposure={S}, "
                                 f"{args.channels}+depth channels, fwd+bwd to all leaves", "gaussians": N, "exposure_subsamples": S,
