@@ -39,8 +39,10 @@ CONFIGS = {
 SEEDS = {"cfg2": 1001, "cfg3": 1002, "cfg5": 1004, "tiny": 1099}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F32_PEAK_TFLOPS = 157.3  # fp32 vector peak == fp32-input dense MFMA peak (MI355X_MICROARCH.md)
-FLOPS_PER_PAIR_BWD = 96.0  # per (splat, pixel) in k_raster_bwd<3,true>: counted from the kernel source
-FLOPS_PER_PAIR_FWD = 34.0
+# ALGORITHMIC FP32 ops per (splat, pixel) of the reference composite (gsplat rasterize_to_pixels fwd / bwd at 4
+# channels), SURVEY.md section 8(d): ~30 forward, ~90 backward.  The HIP kernels execute fewer.
+FLOPS_PER_PAIR_BWD = 90.0
+FLOPS_PER_PAIR_FWD = 30.0
 
 
 def parse():
