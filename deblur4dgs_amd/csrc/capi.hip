@@ -11,6 +11,8 @@ int d4gs_raster_bwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect 
                          const D4gsRasterGrads *, hipStream_t);
 int d4gs_project_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, const float *, const float *,
                           const float *, const float *, const float *, const D4gsLeafGrads *, hipStream_t);
+int d4gs_points_fwd_impl(const D4gsDims *, const D4gsProjIn *, float *, hipStream_t);
+int d4gs_points_bwd_impl(const D4gsDims *, const D4gsProjIn *, const float *, const D4gsLeafGrads *, hipStream_t);
 int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *,
                         hipStream_t);
 int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
@@ -163,6 +165,29 @@ int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
   if (rc) return rc;
   return d4gs_project_bwd_impl(dims, in, proj, v_means2d, v_conics, v_depths, v_opac_act, v_ctab, grads,
                                (hipStream_t)stream);
+}
+
+static int check_points(const D4gsDims *d, const D4gsProjIn *in) {
+  if (!d || !in || d->N <= 0 || d->S <= 0 || d->G < 0 || d->G > d->N || !in->means || !in->viewmat || !in->Kmat ||
+      (d->G > 0 && (d->K <= 0 || d->K > D4GS_MAX_K || d->T <= 0 || !in->motion_coefs || !in->rots || !in->transls ||
+                    !in->times))) {
+    d4gs_set_error("d4gs_points_*: bad dims or NULL required input");
+    return D4GS_EINVAL;
+  }
+  return D4GS_OK;
+}
+
+int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points, void *stream) {
+  int rc = check_points(dims, in);
+  if (rc) return rc;
+  return d4gs_points_fwd_impl(dims, in, points, (hipStream_t)stream);
+}
+
+int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points, const D4gsLeafGrads *grads,
+                    void *stream) {
+  int rc = check_points(dims, in);
+  if (rc) return rc;
+  return d4gs_points_bwd_impl(dims, in, v_points, grads, (hipStream_t)stream);
 }
 
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy, const float *renders,

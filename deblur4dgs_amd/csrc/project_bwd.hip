@@ -26,6 +26,7 @@ struct BwdArgs {
   const float *v_means2d, *v_conics, *v_depths, *v_opac_act, *v_ctab;
   D4gsLeafGrads g;
   int n_shared;  // S*(9K+12)+12
+  const float *v_points;  // non-null: "points only" mode - adjoint of d4gs_points_fwd ([S,N,3] camera-space means)
 };
 
 __device__ __forceinline__ void preblend_bases_b(const BwdArgs &a, float *Bs) {
@@ -68,10 +69,11 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
   const bool active = g < N;
   const bool isdyn = active && g < G;
   const bool raw = d.flags & D4GS_RAW_PARAMS;
+  const bool pts = a.v_points != nullptr;
 
   float mu[3] = {0, 0, 0}, Rq[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, sc[3] = {1, 1, 1}, qh[4] = {1, 0, 0, 0}, inv_qn = 1.f;
-  if (active) {
-    mu[0] = a.in.means[g * 3], mu[1] = a.in.means[g * 3 + 1], mu[2] = a.in.means[g * 3 + 2];
+  if (active) mu[0] = a.in.means[g * 3], mu[1] = a.in.means[g * 3 + 1], mu[2] = a.in.means[g * 3 + 2];
+  if (active && !pts) {
     const float4 q = *reinterpret_cast<const float4 *>(a.in.quats + (size_t)g * 4);
     inv_qn = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
     qh[0] = q.x * inv_qn, qh[1] = q.y * inv_qn, qh[2] = q.z * inv_qn, qh[3] = q.w * inv_qn;
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
 #pragma unroll
     for (int r = 0; r < NV; r++) vec[r] = 0.f;
     const size_t i = (size_t)s * N + (active ? g : 0);
-    if (active && a.radii[i] > 0) {
+    if (active && (pts || a.radii[i] > 0)) {
       // ---- recompute the forward ----
       float mw0[3], Rm[9], Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, v9[9];
       GS6 gs;
@@ -143,76 +145,80 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 3; r++) mw[r] = RT[r * 4] * mw0[0] + RT[r * 4 + 1] * mw0[1] + RT[r * 4 + 2] * mw0[2] + RT[r * 4 + 3];
       }
-      ProjOut p;
-      D4gsDims dd = d;
-      dd.near_plane = -INFINITY, dd.far_plane = INFINITY;  // the visibility decision is the saved radius
-      project_instance(cam, mw, Rm, sc, dd, p);
-      // ---- adjoint of conic = inverse(cov2d_blur) ----
-      const float A = a.conics[i * 3], Bc = a.conics[i * 3 + 1], C = a.conics[i * 3 + 2];
-      const float vA = a.v_conics[i * 3], vB = 0.5f * a.v_conics[i * 3 + 1], vC = a.v_conics[i * 3 + 2];
-      const float t00 = A * vA + Bc * vB, t01 = A * vB + Bc * vC, t10 = Bc * vA + C * vB, t11 = Bc * vB + C * vC;
-      const float w00 = -(t00 * A + t01 * Bc), w01 = -(t00 * Bc + t01 * C), w11 = -(t10 * Bc + t11 * C);
-      // ---- cov2d = J covc J^T ----
-      const float rz = p.rz, rz2 = rz * rz, rz3 = rz2 * rz;
-      const float J00 = cam.fx * rz, J11 = cam.fy * rz, J02 = p.J02, J12 = p.J12;
-      const float cxx = p.covc[0], cxy = p.covc[1], cxz = p.covc[2], cyy = p.covc[3], cyz = p.covc[4], czz = p.covc[5];
-      // JS = J covc (2x3)
-      const float js00 = J00 * cxx + J02 * cxz, js01 = J00 * cxy + J02 * cyz, js02 = J00 * cxz + J02 * czz;
-      const float js10 = J11 * cxy + J12 * cxz, js11 = J11 * cyy + J12 * cyz, js12 = J11 * cyz + J12 * czz;
-      // v_J = 2 * w * JS  (only the structurally non-zero entries)
-      const float vJ00 = 2.f * (w00 * js00 + w01 * js10);
-      const float vJ02 = 2.f * (w00 * js02 + w01 * js12);
-      const float vJ11 = 2.f * (w01 * js01 + w11 * js11);
-      const float vJ12 = 2.f * (w01 * js02 + w11 * js12);
-      // v_covc = J^T w J (symmetric 3x3)
-      const float a0 = w00 * J00, a1 = w01 * J11, a2 = w00 * J02 + w01 * J12;  // row 0 of (w J)
-      const float b0 = w01 * J00, b1 = w11 * J11, b2 = w01 * J02 + w11 * J12;  // row 1 of (w J)
-      float vS[9];
-      vS[0] = J00 * a0, vS[1] = J00 * a1, vS[2] = J00 * a2;
-      vS[3] = J11 * b0, vS[4] = J11 * b1, vS[5] = J11 * b2;
-      vS[6] = J02 * a0 + J12 * b0, vS[7] = J02 * a1 + J12 * b1, vS[8] = J02 * a2 + J12 * b2;
-      // ---- camera-space mean ----
-      const float vm0 = a.v_means2d[i * 2], vm1 = a.v_means2d[i * 2 + 1];
-      const float x = p.pc[0], y = p.pc[1], z = p.pc[2];
-      const float tx = -J02 / (cam.fx * rz2), ty = -J12 / (cam.fy * rz2);
-      float v_pc[3];
-      v_pc[0] = cam.fx * rz * vm0;
-      v_pc[1] = cam.fy * rz * vm1;
-      v_pc[2] = -(cam.fx * x * vm0 + cam.fy * y * vm1) * rz2 + a.v_depths[i];
-      if (p.in_x) v_pc[0] += -cam.fx * rz2 * vJ02; else v_pc[2] += -cam.fx * rz3 * vJ02 * tx;
-      if (p.in_y) v_pc[1] += -cam.fy * rz2 * vJ12; else v_pc[2] += -cam.fy * rz3 * vJ12 * ty;
-      v_pc[2] += -cam.fx * rz2 * vJ00 - cam.fy * rz2 * vJ11 + 2.f * cam.fx * tx * rz3 * vJ02 + 2.f * cam.fy * ty * rz3 * vJ12;
-      (void)z;
-      // ---- covc = M M^T, M = (Rcw Rm) diag(sc) ----
-      float vM[9];
-      {
-        float sym[9];
+      float v_pc[3], vRm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (pts) {
 #pragma unroll
+        for (int r = 0; r < 3; r++) v_pc[r] = a.v_points[i * 3 + r];
+      } else {
+        ProjOut p;
+        D4gsDims dd = d;
+        dd.near_plane = -INFINITY, dd.far_plane = INFINITY;  // the visibility decision is the saved radius
+        project_instance(cam, mw, Rm, sc, dd, p);
+        // ---- adjoint of conic = inverse(cov2d_blur) ----
+        const float A = a.conics[i * 3], Bc = a.conics[i * 3 + 1], C = a.conics[i * 3 + 2];
+        const float vA = a.v_conics[i * 3], vB = 0.5f * a.v_conics[i * 3 + 1], vC = a.v_conics[i * 3 + 2];
+        const float t00 = A * vA + Bc * vB, t01 = A * vB + Bc * vC, t10 = Bc * vA + C * vB, t11 = Bc * vB + C * vC;
+        const float w00 = -(t00 * A + t01 * Bc), w01 = -(t00 * Bc + t01 * C), w11 = -(t10 * Bc + t11 * C);
+        // ---- cov2d = J covc J^T ----
+        const float rz = p.rz, rz2 = rz * rz, rz3 = rz2 * rz;
+        const float J00 = cam.fx * rz, J11 = cam.fy * rz, J02 = p.J02, J12 = p.J12;
+        const float cxx = p.covc[0], cxy = p.covc[1], cxz = p.covc[2], cyy = p.covc[3], cyz = p.covc[4], czz = p.covc[5];
+        // JS = J covc (2x3)
+        const float js00 = J00 * cxx + J02 * cxz, js01 = J00 * cxy + J02 * cyz, js02 = J00 * cxz + J02 * czz;
+        const float js10 = J11 * cxy + J12 * cxz, js11 = J11 * cyy + J12 * cyz, js12 = J11 * cyz + J12 * czz;
+        // v_J = 2 * w * JS  (only the structurally non-zero entries)
+        const float vJ00 = 2.f * (w00 * js00 + w01 * js10);
+        const float vJ02 = 2.f * (w00 * js02 + w01 * js12);
+        const float vJ11 = 2.f * (w01 * js01 + w11 * js11);
+        const float vJ12 = 2.f * (w01 * js02 + w11 * js12);
+        // v_covc = J^T w J (symmetric 3x3)
+        const float a0 = w00 * J00, a1 = w01 * J11, a2 = w00 * J02 + w01 * J12;  // row 0 of (w J)
+        const float b0 = w01 * J00, b1 = w11 * J11, b2 = w01 * J02 + w11 * J12;  // row 1 of (w J)
+        float vS[9];
+        vS[0] = J00 * a0, vS[1] = J00 * a1, vS[2] = J00 * a2;
+        vS[3] = J11 * b0, vS[4] = J11 * b1, vS[5] = J11 * b2;
+        vS[6] = J02 * a0 + J12 * b0, vS[7] = J02 * a1 + J12 * b1, vS[8] = J02 * a2 + J12 * b2;
+        // ---- camera-space mean ----
+        const float vm0 = a.v_means2d[i * 2], vm1 = a.v_means2d[i * 2 + 1];
+        const float x = p.pc[0], y = p.pc[1], z = p.pc[2];
+        const float tx = -J02 / (cam.fx * rz2), ty = -J12 / (cam.fy * rz2);
+        v_pc[0] = cam.fx * rz * vm0;
+        v_pc[1] = cam.fy * rz * vm1;
+        v_pc[2] = -(cam.fx * x * vm0 + cam.fy * y * vm1) * rz2 + a.v_depths[i];
+        if (p.in_x) v_pc[0] += -cam.fx * rz2 * vJ02; else v_pc[2] += -cam.fx * rz3 * vJ02 * tx;
+        if (p.in_y) v_pc[1] += -cam.fy * rz2 * vJ12; else v_pc[2] += -cam.fy * rz3 * vJ12 * ty;
+        v_pc[2] += -cam.fx * rz2 * vJ00 - cam.fy * rz2 * vJ11 + 2.f * cam.fx * tx * rz3 * vJ02 + 2.f * cam.fy * ty * rz3 * vJ12;
+        (void)z;
+        // ---- covc = M M^T, M = (Rcw Rm) diag(sc) ----
+        float vM[9];
+        {
+          float sym[9];
+  #pragma unroll
+          for (int r = 0; r < 3; r++)
+  #pragma unroll
+            for (int c = 0; c < 3; c++) sym[r * 3 + c] = vS[r * 3 + c] + vS[c * 3 + r];
+          mat3_mul(sym, p.M, vM);
+        }
+        float Wm[9], vW[9];
+        mat3_mul(cam.R, Rm, Wm);
+  #pragma unroll
         for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) sym[r * 3 + c] = vS[r * 3 + c] + vS[c * 3 + r];
-        mat3_mul(sym, p.M, vM);
-      }
-      float Wm[9], vW[9];
-      mat3_mul(cam.R, Rm, Wm);
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) vW[r * 3 + c] = vM[r * 3 + c] * sc[c];
-#pragma unroll
-      for (int c = 0; c < 3; c++) v_sc[c] += Wm[c] * vM[c] + Wm[3 + c] * vM[3 + c] + Wm[6 + c] * vM[6 + c];
-      float vRm[9];
-      mat3_mul_at(cam.R, vW, vRm);  // Rcw^T vW
-      {
-        float tmp[9];
-        mat3_mul_bt(vW, Rm, tmp);    // vW Rm^T  -> dL/dRcw
-#pragma unroll
-        for (int r = 0; r < 9; r++) v_view[r] += tmp[r];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-#pragma unroll
-          for (int c = 0; c < 3; c++) v_view[r * 3 + c] += v_pc[r] * mw[c];
-          v_view[9 + r] += v_pc[r];
+  #pragma unroll
+          for (int c = 0; c < 3; c++) vW[r * 3 + c] = vM[r * 3 + c] * sc[c];
+  #pragma unroll
+        for (int c = 0; c < 3; c++) v_sc[c] += Wm[c] * vM[c] + Wm[3 + c] * vM[3 + c] + Wm[6 + c] * vM[6 + c];
+        mat3_mul_at(cam.R, vW, vRm);  // Rcw^T vW
+        {
+          float tmp[9];
+          mat3_mul_bt(vW, Rm, tmp);    // vW Rm^T  -> dL/dRcw
+  #pragma unroll
+          for (int r = 0; r < 9; r++) v_view[r] += tmp[r];
+  #pragma unroll
+          for (int r = 0; r < 3; r++) {
+  #pragma unroll
+            for (int c = 0; c < 3; c++) v_view[r * 3 + c] += v_pc[r] * mw[c];
+            v_view[9 + r] += v_pc[r];
+          }
         }
       }
       float v_mw[3];
@@ -338,7 +344,7 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
   if (!active) return;
   // ---- per-Gaussian leaves ----
   a.g.v_means[g * 3] = v_mu[0], a.g.v_means[g * 3 + 1] = v_mu[1], a.g.v_means[g * 3 + 2] = v_mu[2];
-  {
+  if (!pts) {
     const float w = qh[0], x = qh[1], y = qh[2], z = qh[3];
     const float *vR = v_Rq;
     float vq[4];
@@ -351,14 +357,12 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
                             (vq[3] - dot * z) * inv_qn);
     *reinterpret_cast<float4 *>(a.g.v_quats + (size_t)g * 4) = o4;
   }
+  if (!pts) {
 #pragma unroll
-  for (int j = 0; j < 3; j++) a.g.v_scales[g * 3 + j] = raw ? v_sc[j] * sc[j] : v_sc[j];
-  {
+    for (int j = 0; j < 3; j++) a.g.v_scales[g * 3 + j] = raw ? v_sc[j] * sc[j] : v_sc[j];
     const float o = a.opac_act[g];
     const float vo = a.v_opac_act[g];
     a.g.v_opacities[g] = raw ? vo * o * (1.f - o) : vo;
-  }
-  {
     const int D = d.D, DP = (D + 3) & ~3;
     for (int ch = 0; ch < D; ch++) {
       float v = a.v_ctab[(size_t)g * DP + ch];
@@ -459,15 +463,32 @@ extern "C" size_t d4gs_bwd_partials_elems(const D4gsDims *d) {
   return (blocks + 1) * (size_t)n_shared_of(d);
 }
 
+static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGrads *grads, hipStream_t stream);
+
+int d4gs_points_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points, const D4gsLeafGrads *grads,
+                         hipStream_t stream) {
+  BwdArgs a{};
+  a.d = *dims;
+  a.in = *in;
+  a.g = *grads;
+  a.v_points = v_points;
+  return launch_project_bwd(a, dims, grads, stream);
+}
+
 int d4gs_project_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *proj, const float *v_means2d,
                           const float *v_conics, const float *v_depths, const float *v_opac_act, const float *v_ctab,
                           const D4gsLeafGrads *grads, hipStream_t stream) {
-  BwdArgs a;
+  BwdArgs a{};
   a.d = *dims;
   a.in = *in;
   a.radii = proj->radii, a.conics = proj->conics, a.ctab = proj->ctab, a.opac_act = proj->opac_act;
   a.v_means2d = v_means2d, a.v_conics = v_conics, a.v_depths = v_depths, a.v_opac_act = v_opac_act, a.v_ctab = v_ctab;
   a.g = *grads;
+  a.v_points = nullptr;
+  return launch_project_bwd(a, dims, grads, stream);
+}
+
+static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGrads *grads, hipStream_t stream) {
   a.n_shared = n_shared_of(dims);
   const int K = dims->G > 0 ? dims->K : 0;
   const int KP = K | 1;

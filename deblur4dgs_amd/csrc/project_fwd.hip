@@ -19,6 +19,7 @@ struct FwdArgs {
   D4gsProjIn in;
   D4gsProjOut out;
   int tw, th;
+  float *points;  // non-null: "points only" mode (track channels, a11): write the camera-space mean [S,N,3] and stop
 };
 
 // time-blended bases: Bs[s][k][0:3] = transl, [3:9] = 6-D rotation   (params.py:152-177; w uses the clamped floor)
@@ -58,10 +59,13 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
   const bool active = g < N;
   const bool raw = d.flags & D4GS_RAW_PARAMS;
   float mu[3] = {0, 0, 0}, Rq[9], sc[3] = {1, 1, 1}, opac = 0.f;
+  const bool pts = a.points != nullptr;
   if (active) {
     mu[0] = a.in.means[g * 3];
     mu[1] = a.in.means[g * 3 + 1];
     mu[2] = a.in.means[g * 3 + 2];
+  }
+  if (active && !pts) {
     const float4 q = *reinterpret_cast<const float4 *>(a.in.quats + (size_t)g * 4);
     float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
     quat_to_rotmat(q.x * inv, q.y * inv, q.z * inv, q.w * inv, Rq);
@@ -82,6 +86,8 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       }
       a.out.ctab[(size_t)g * DP + ch] = v;
     }
+  }
+  if (active) {
     if (g < G) {  // softmax(motion_coefs)  params.py:43
       const float *mc = a.in.motion_coefs + (size_t)g * K;
       float m = -INFINITY;
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       float Rd[9] = {gs.x[0], gs.y[0], gs.z[0], gs.x[1], gs.y[1], gs.z[1], gs.x[2], gs.y[2], gs.z[2]};
 #pragma unroll
       for (int i = 0; i < 3; i++) mw[i] = Rd[i * 3] * mu[0] + Rd[i * 3 + 1] * mu[1] + Rd[i * 3 + 2] * mu[2] + v9[i];
-      mat3_mul(Rd, Rq, Rm);
+      if (!pts) mat3_mul(Rd, Rq, Rm);
     } else {
 #pragma unroll
       for (int i = 0; i < 3; i++) mw[i] = mu[i];
@@ -131,9 +137,15 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       float t2 = RT[8] * mw[0] + RT[9] * mw[1] + RT[10] * mw[2] + RT[11];
       mw[0] = t0, mw[1] = t1, mw[2] = t2;
     }
+    const size_t i = (size_t)s * N + g;
+    if (pts) {  // scene_model.py:258-289: positions at the target times in the target cameras
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        a.points[i * 3 + r] = cam.R[r * 3] * mw[0] + cam.R[r * 3 + 1] * mw[1] + cam.R[r * 3 + 2] * mw[2] + cam.t[r];
+      continue;
+    }
     ProjOut p;
     project_instance(cam, mw, Rm, sc, d, p);
-    const size_t i = (size_t)s * N + g;
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
     float m2x = 0.f, m2y = 0.f, dep = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
     int cnt = 0;
@@ -251,11 +263,34 @@ extern "C" size_t d4gs_scan_ws_elems(int64_t n_instances) {
   return (size_t)((n_instances + SCAN_TILE - 1) / SCAN_TILE) + 16;
 }
 
+static size_t fwd_lds_bytes(const D4gsDims *dims) {
+  if (dims->G <= 0) return 0;
+  return sizeof(float) * (((size_t)dims->S * dims->K * 9 + 3) & ~(size_t)3) + sizeof(float) * (size_t)dims->K * D4GS_PROJ_BLOCK;
+}
+
+int d4gs_points_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, float *points, hipStream_t stream) {
+  FwdArgs a;
+  a.d = *dims;
+  a.in = *in;
+  a.out = D4gsProjOut{};
+  a.tw = a.th = 0;
+  a.points = points;
+  const size_t lds = fwd_lds_bytes(dims);
+  if (lds > 64 * 1024) {
+    d4gs_set_error("S*K too large for the LDS-resident bases (S=%d K=%d)", dims->S, dims->K);
+    return D4GS_EINVAL;
+  }
+  const int blocks = (dims->N + D4GS_PROJ_BLOCK - 1) / D4GS_PROJ_BLOCK;
+  D4GS_LAUNCH("k_project_fwd[points]", k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
+  return d4gs_check_launch("k_project_fwd[points]");
+}
+
 int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, hipStream_t stream) {
   FwdArgs a;
   a.d = *dims;
   a.in = *in;
   a.out = *out;
+  a.points = nullptr;
   a.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
   a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   const int64_t n_inst = (int64_t)dims->S * dims->N;

@@ -226,6 +226,62 @@ class RasterFn(torch.autograd.Function):
         return None, g["v_means2d"], g["v_conics"], g["v_depths"], g["v_opac_act"], g["v_ctab"], None
 
 
+class PointsFn(torch.autograd.Function):
+    """a11 (flow3d/scene_model.py:258-289): camera-space positions of all N Gaussians at B target times,
+    `points[b,g] = target_w2cs[b,:3] @ [deform(g, target_ts[b]); 1]` -> [B,N,3].  d4gs_points_fwd / d4gs_points_bwd
+    (the deformation half of the projection kernels in "points only" mode)."""
+
+    @staticmethod
+    def forward(ctx, means, motion_coefs, rots, transls, target_ts, target_w2cs34):
+        _need_gpu(means)
+        dev = means.device
+        N, B = means.shape[0], target_ts.shape[0]
+        G = 0 if motion_coefs is None else motion_coefs.shape[0]
+        K, T = (rots.shape[0], rots.shape[1]) if G > 0 else (0, 0)
+        cfg = RenderCfg(N=N, G=G, K=K, T=T, S=B, D=1, width=16, height=16, flags=L.RAW_PARAMS, exact_cull=False)
+        eye4 = torch.eye(4, device=dev)
+        pin = dict(means=_f32c(means), quats=None, scales=None, opacities=None, colors=None,
+                   motion_coefs=_f32c(motion_coefs), rots=_f32c(rots), transls=_f32c(transls), times=_f32c(target_ts),
+                   RTs=_f32c(target_w2cs34), viewmat=eye4, Kmat=eye4[:3, :3].contiguous())
+        pts = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        dims = cfg.dims()
+        L.check(L.lib().d4gs_points_fwd(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pin)), L.ptr(pts), _stream()),
+                "d4gs_points_fwd")
+        ctx.cfg, ctx.pin = cfg, pin
+        ctx.needs = [t is not None and t.requires_grad for t in (means, motion_coefs, rots, transls, target_ts,
+                                                                 target_w2cs34)]
+        return pts
+
+    @staticmethod
+    def backward(ctx, v_pts):
+        cfg, pin = ctx.cfg, ctx.pin
+        dev = v_pts.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        lib = L.lib()
+        dims = cfg.dims()
+        dyn = cfg.G > 0
+        g = dict(v_means=torch.empty(cfg.N, 3, **f32), v_quats=None, v_scales=None, v_opacities=None, v_colors=None,
+                 v_motion_coefs=torch.empty(cfg.G, cfg.K, **f32) if dyn else None,
+                 v_rots=torch.empty(cfg.K, cfg.T, 6, **f32) if dyn else None,
+                 v_transls=torch.empty(cfg.K, cfg.T, 3, **f32) if dyn else None,
+                 v_times=torch.empty(cfg.S, **f32) if dyn else None,
+                 v_RTs=torch.empty(cfg.S, 3, 4, **f32) if pin["RTs"] is not None else None,
+                 v_viewmat=torch.empty(4, 4, **f32),
+                 partials=torch.empty(lib.d4gs_bwd_partials_elems(C.byref(dims)), **f32))
+        L.check(lib.d4gs_points_bwd(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pin)),
+                                    L.ptr(v_pts.to(torch.float32).contiguous()), C.byref(L.fill(L.LeafGrads(), **g)),
+                                    _stream()), "d4gs_points_bwd")
+        outs = [g["v_means"], g["v_motion_coefs"], g["v_rots"], g["v_transls"], g["v_times"], g["v_RTs"]]
+        return tuple(x if need else None for x, need in zip(outs, ctx.needs))
+
+
+def track_points(means, motion_coefs, rots, transls, target_ts, target_w2cs=None):
+    """-> [N,B,3] positions of all Gaussians (the first G = len(motion_coefs) deformed) at `target_ts`, expressed in
+    the cameras `target_w2cs [B,4,4]` (world frame if None)."""
+    w34 = None if target_w2cs is None else target_w2cs[:, :3, :]
+    return PointsFn.apply(means, motion_coefs, rots, transls, target_ts, w34).permute(1, 0, 2)
+
+
 def render_instances(cfg: RenderCfg, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs,
                      viewmat, Kmat, background):
     """Deform + project + bin + sort + composite all S sub-samples.

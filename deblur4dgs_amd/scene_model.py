@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .engine import track_points
 from .exposure import reference_policy, render_exposure
 from .move_model import MoveModel
 
@@ -201,9 +202,13 @@ class SceneModel(nn.Module):
         B = 0
         if target_ts is not None:  # :258-289
             B = target_ts.shape[0]
-            if target_means is None:
-                target_means = self.compute_means_at(target_ts, which)  # [N,B,3]
-            if target_w2cs is not None:
+            if target_means is None:  # fused HIP path: deform at the B target times + express in the target cameras
+                tG = 0 if which == "bg" else self.num_fg_gaussians
+                target_means = track_points(
+                    P["means"], self.fg.params["motion_coefs"] if tG > 0 else None,
+                    self.motion_bases.params["rots"] if tG > 0 else None,
+                    self.motion_bases.params["transls"] if tG > 0 else None, target_ts.to(torch.float32), target_w2cs)
+            elif target_w2cs is not None:
                 target_means = torch.einsum("bij,pbj->pbi", target_w2cs[:, :3], F.pad(target_means, (0, 1), value=1.0))
             colors_override = torch.cat([colors_override, target_means.flatten(-2)], -1)
             bg_color = torch.cat([bg_color, torch.zeros(1, 3 * B, device=device)], -1)

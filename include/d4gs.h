@@ -169,6 +169,15 @@ int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
                      const float *v_means2d, const float *v_conics, const float *v_depths, const float *v_opac_act,
                      const float *v_ctab, const D4gsLeafGrads *grads, void *stream);
 
+/* a11 track channels (scene_model.py:258-289): camera-space position of every Gaussian at S target times,
+ * points[s,g] = RTs[s] * deform(g, times[s]) (then viewmat, normally identity).  Uses dims N/G/K/T/S and
+ * in->means, motion_coefs, rots, transls, times (= target_ts), RTs (= target_w2cs[:, :3, :], may be NULL), viewmat,
+ * Kmat; every other input may be NULL.  The backward fills v_means, v_motion_coefs, v_rots, v_transls, v_times,
+ * v_RTs, v_viewmat of D4gsLeafGrads (the other leaf pointers are not touched). */
+int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points /* [S,N,3] */, void *stream);
+int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points /* [S,N,3] */,
+                    const D4gsLeafGrads *grads, void *stream);
+
 /* a9 exposure blend (scene_model.py:386-397): out = mean_S; policy[c] 1 -> max over {raw_0..raw_{S-2}, mean},
  * 2 -> min over the same set (the reference's in-place quirk); acc = mean_S alphas. */
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] [C] */,

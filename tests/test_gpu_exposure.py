@@ -84,3 +84,35 @@ def test_exposure_forward_backward(N, G, K, S, W, H, mask, depth):
     assert rel_err(tms.grad.cpu(), times.grad) < 2e-3, (tms.grad.cpu(), times.grad)
     assert rel_err(rts.grad.cpu(), RTs.grad) < 2e-3
     assert rel_err(vm.grad.cpu()[:3], w2c.grad[:3]) < 2e-3
+
+
+def test_track_points_match_oracle():
+    """a11 (scene_model.py:258-289): positions at B target times in B target cameras, forward + all gradients."""
+    from deblur4dgs_amd.engine import track_points
+    from deblur4dgs_amd.move_model import se3_to_SE3
+    from oracle import deform
+
+    dev = torch.device("cuda:0")
+    N, G, K, B = 700, 450, 5, 4
+    sc = make_scene(N, G, K, 1, 64, 64, seed=91, dtype=torch.float64)
+    fg, bg, bases = _split(sc, torch.float64)
+    ts = torch.tensor([0.0, 2.4, 7.0, 30.0], dtype=torch.float64)  # integer, fractional, and clamped (> T-1)
+    w2c = torch.cat([se3_to_SE3(0.1 * torch.randn(B, 6)).double(), torch.tensor([0, 0, 0, 1.0]).expand(B, 1, 4).double()], 1)
+    m, _ = deform.compute_poses_all(ts, fg, bases, bg)  # [N,B,3]
+    ref = torch.einsum("bij,pbj->pbi", w2c[:, :3], torch.nn.functional.pad(m, (0, 1), value=1.0))
+    wgt = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    (ref * wgt).sum().backward()
+
+    means = torch.cat([fg["means"], bg["means"]], 0).detach().float().to(dev).requires_grad_()
+    coefs = fg["motion_coefs"].detach().float().to(dev).requires_grad_()
+    rots = bases["rots"].detach().float().to(dev).requires_grad_()
+    transls = bases["transls"].detach().float().to(dev).requires_grad_()
+    out = track_points(means, coefs, rots, transls, ts.float().to(dev), w2c.float().to(dev))
+    assert out.shape == (N, B, 3)
+    (out * wgt.float().to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 1e-5
+    assert rel_err(means.grad.cpu(), torch.cat([fg["means"].grad, bg["means"].grad], 0)) < 1e-4
+    assert rel_err(coefs.grad.cpu(), fg["motion_coefs"].grad) < 1e-4
+    assert rel_err(rots.grad.cpu(), bases["rots"].grad) < 1e-4
+    assert rel_err(transls.grad.cpu(), bases["transls"].grad) < 1e-4
