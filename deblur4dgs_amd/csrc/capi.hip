@@ -13,6 +13,8 @@ int d4gs_project_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOu
                           const float *, const float *, const float *, const D4gsLeafGrads *, hipStream_t);
 int d4gs_points_fwd_impl(const D4gsDims *, const D4gsProjIn *, float *, hipStream_t);
 int d4gs_points_bwd_impl(const D4gsDims *, const D4gsProjIn *, const float *, const D4gsLeafGrads *, hipStream_t);
+int d4gs_control_stats_impl(int32_t, int32_t, const float *, const int32_t *, int32_t, int32_t, int32_t, float *,
+                            int64_t *, float *, int32_t, hipStream_t);
 int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *,
                         hipStream_t);
 int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
@@ -188,6 +190,13 @@ int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_p
   int rc = check_points(dims, in);
   if (rc) return rc;
   return d4gs_points_bwd_impl(dims, in, v_points, grads, (hipStream_t)stream);
+}
+
+int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad, const int32_t *radii, int32_t width, int32_t height,
+                       int32_t batch_size, float *grad_norm_acc, int64_t *vis_count, float *max_radii,
+                       int32_t update_max_radii, void *stream) {
+  return d4gs_control_stats_impl(S, N, xys_grad, radii, width, height, batch_size, grad_norm_acc, vis_count, max_radii,
+                                 update_max_radii, (hipStream_t)stream);
 }
 
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy, const float *renders,

@@ -178,6 +178,17 @@ int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points /*
 int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points /* [S,N,3] */,
                     const D4gsLeafGrads *grads, void *stream);
 
+/* Densification statistics, Trainer._prepare_control_step (flow3d/trainer.py:953-990) for one render of
+ * S sub-samples: for every visible instance (radii > 0)
+ *   grad_norm_acc[g] += || xys_grad[s,g] * (W/2, H/2) * batch_size * S ||,  vis_count[g] += 1,
+ *   max_radii[g] = max(max_radii[g], radii[s,g] / max(W, H))  -- ONLY when update_max_radii != 0: the reference
+ *   computes this maximum and then drops it (out-of-place `index_put`, trainer.py:987-989), so its `max_radii`
+ *   stays at its initial value; 0 reproduces that.   Running stats are updated in place. */
+int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad /* [S,N,2] */, const int32_t *radii /* [S,N] */,
+                       int32_t width, int32_t height, int32_t batch_size, float *grad_norm_acc /* [N] */,
+                       int64_t *vis_count /* [N] */, float *max_radii /* [N] */, int32_t update_max_radii,
+                       void *stream);
+
 /* a9 exposure blend (scene_model.py:386-397): out = mean_S; policy[c] 1 -> max over {raw_0..raw_{S-2}, mean},
  * 2 -> min over the same set (the reference's in-place quirk); acc = mean_S alphas. */
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] [C] */,

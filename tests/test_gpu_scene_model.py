@@ -110,3 +110,32 @@ def test_render_view_and_inference_mode():
         o = model.render(2, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (80, 48), fg_only=True, return_mask=True,
                          filter_mask=torch.arange(300, device=dev) % 3 != 0)
         assert o["mask"].shape == (1, 48, 80, 1)
+
+
+def test_control_stats_match_reference_accumulation():
+    """fused densification statistics vs the literal restatement of trainer.py:967-989."""
+    from deblur4dgs_amd.control import accumulate_from_model
+    from oracle import control as octl
+
+    dev = torch.device("cuda:0")
+    N, G, K, W, H = 1500, 800, 3, 96, 64
+    model, sc = _build(N, G, K, W, H, 23, dev)
+    stats = {"xys_grad_norm_acc": torch.rand(N, device=dev), "vis_count": torch.randint(0, 5, (N,), device=dev),
+             "max_radii": torch.rand(N, device=dev) * 0.05}
+    ref = {k: v.clone().cpu() for k, v in stats.items()}
+    for _ in range(2):  # two renders accumulate
+        out = model.render(3.0, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H), return_depth=True,
+                           mode="blury")
+        out["img"].square().sum().backward()
+        accumulate_from_model(stats, model, batch_size=2)
+        octl.prepare_control_step(ref, [x.grad.cpu() for x in model._current_xys],
+                                  [r.cpu() for r in model._current_radii], (W, H), 2)
+    torch.cuda.synchronize()
+    assert torch.equal(stats["vis_count"].cpu(), ref["vis_count"])
+    assert torch.equal(stats["max_radii"].cpu(), ref["max_radii"])  # reference quirk: never updated (index_put)
+    assert torch.allclose(stats["xys_grad_norm_acc"].cpu(), ref["xys_grad_norm_acc"], rtol=1e-5, atol=1e-7)
+    # the intended semantics are available behind a flag
+    before = stats["max_radii"].clone()
+    accumulate_from_model(stats, model, batch_size=2, update_max_radii=True)
+    rad = torch.cat(list(model._current_radii), 0).float().amax(0) / max(W, H)
+    assert torch.allclose(stats["max_radii"], torch.maximum(before, rad), rtol=1e-6, atol=0)
