@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
   float *cf = Bs + nBs;              // [BLK][KP]   softmaxed coefficients
   float *vcf = cf + BLK * KP;        // [BLK][KP]   their gradients, summed over s
   float *sv = vcf + BLK * KP;        // [BLK][NV]   per-s vectors to be column-reduced
+  float *psum = sv + BLK * NV;       // [4][9K+12]  per-wave segment sums
   const int tid = threadIdx.x;
   const int g = blockIdx.x * BLK + tid;
   const Cam cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
@@ -310,20 +311,29 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < NV; r++) sv[tid * NV + r] = vec[r];
       __syncthreads();
-      const int nk = dyn ? K * 9 : 0;
-      for (int o = tid; o < nk + 12; o += BLK) {
-        float acc = 0.f;
+      const int nk = dyn ? K * 9 : 0, no = nk + 12;
+      // (output o, segment) tasks: wave `seg` sums t in [64 seg, 64 seg + 64) for outputs lane, lane + 64, ...;
+      // the 4 segment sums are then added in fixed order -> deterministic, and 4x shorter dependent chains
+      const int seg = tid >> 6, t0 = seg * 64;
+      for (int o = tid & 63; o < no; o += 64) {
+        float a0 = 0.f, a1 = 0.f;
         if (o < nk) {
           if (dyn_block) {
             const int k = o / 9, j = o - k * 9;
-            for (int t = 0; t < BLK; t++) acc += cf[t * KP + k] * sv[t * NV + j];
+            for (int t = t0; t < t0 + 64; t += 2) {
+              a0 += cf[t * KP + k] * sv[t * NV + j];
+              a1 += cf[(t + 1) * KP + k] * sv[(t + 1) * NV + j];
+            }
           }
         } else {
           const int r = 9 + (o - nk);
-          for (int t = 0; t < BLK; t++) acc += sv[t * NV + r];
+          for (int t = t0; t < t0 + 64; t += 2) a0 += sv[t * NV + r], a1 += sv[(t + 1) * NV + r];
         }
-        part[s * (nk + 12) + o] = acc;
+        psum[seg * no + o] = a0 + a1;
       }
+      __syncthreads();
+      for (int o = tid; o < no; o += BLK)
+        part[s * no + o] = (psum[o] + psum[no + o]) + (psum[2 * no + o] + psum[3 * no + o]);
     }
   }
 
@@ -492,7 +502,8 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   a.n_shared = n_shared_of(dims);
   const int K = dims->G > 0 ? dims->K : 0;
   const int KP = K | 1;
-  size_t lds = sizeof(float) * ((((size_t)dims->S * K * 9 + 3) & ~(size_t)3) + 2 * (size_t)BLK * KP + (size_t)BLK * NV);
+  size_t lds = sizeof(float) * ((((size_t)dims->S * K * 9 + 3) & ~(size_t)3) + 2 * (size_t)BLK * KP + (size_t)BLK * NV +
+                                4 * ((size_t)K * 9 + 12));
   if (lds > 160 * 1024) {
     d4gs_set_error("project_bwd: LDS budget exceeded (S=%d K=%d)", dims->S, dims->K);
     return D4GS_EINVAL;
