@@ -229,6 +229,17 @@ struct ProfScope {
   ProfScope(const char *name, hipStream_t s);
   ~ProfScope();
 };
+// sigma * log2(e) of a splat at a pixel offset (dx, dy); g1 = conic pre-scaled by log2(e).  Used verbatim by both
+// forward variants AND the backward's alpha recomputation: explicit FMAs with contraction off, so every kernel (and
+// every unrolled copy of a loop body) rounds identically - the forward/backward valid-pixel decisions and the
+// "variant A == variant B", "exact cull on == off" bitwise guarantees depend on it.
+__device__ __forceinline__ float splat_sigma2(const float4 g1, float dx, float dy) {
+#pragma clang fp contract(off)
+  const float t = g1.x * dx, u = g1.z * dy;
+  const float q = __builtin_fmaf(t, dx, u * dy);
+  return __builtin_fmaf(0.5f, q, (g1.y * dx) * dy);
+}
+
 // ---- fused DPP wave reduction -------------------------------------------------------------------------------
 // hipcc lowers `x + update_dpp(x)` to v_mov_b32_dpp + v_add_f32 (2 issue slots per step).  These blocks issue the
 // fused v_add_f32_dpp instead: 6 instructions per value, total in lane 63.  Inside one asm block consecutive steps

@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
       for (int p = 0; p < 4; p++) {
         dx[p] = g0.x - pxf[p];
         dy[p] = g0.y - pyf[p];
-        const float sig2 = 0.5f * (g1.x * dx[p] * dx[p] + g1.z * dy[p] * dy[p]) + g1.y * dx[p] * dy[p];  // sigma*log2e
+        const float sig2 = splat_sigma2(g1, dx[p], dy[p]);  // sigma*log2e, bit-identical to the forward
         ov[p] = g0.z * __builtin_amdgcn_exp2f(-sig2);
         const float alpha = fminf(0.999f, ov[p]);
         valid[p] = (cur <= last[p]) && (sig2 >= 0.f) && (alpha >= (1.f / 255.f));

@@ -181,3 +181,31 @@ def test_long_tile_lists_all_sort_paths():
     for t in range(len(counts)):
         d = depth[ids[offs[t]:offs[t + 1]]]
         assert (d[1:] >= d[:-1]).all(), f"tile {t} not depth sorted ({counts[t]} splats)"
+
+
+def test_forward_variants_bitwise_equal():
+    """Variant B of the forward composite (4 quadrant-waves per tile + ballot culling) must equal variant A
+    (one wave per tile) bit for bit - they differ only in which provably-invisible pairs they skip."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tests.util import static_inputs
+from deblur4dgs_amd.rasterization import rasterization
+inp = static_inputs(30000, 320, 200, seed=55, dtype=torch.float32, D=3, scale_mul=2.5)
+t = {k: v.cuda() for k, v in inp.items()}
+rc, ra, info = rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"][None], t["K"][None], 320, 200,
+                             backgrounds=torch.tensor([[0.1, 0.5, 0.9]]).cuda(), render_mode="RGB+ED")
+torch.cuda.synchronize()
+torch.save((rc.cpu(), ra.cpu(), info["last_ids"].cpu()), sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_extra, name in (({}, "/tmp/d4gs_fwd_b.pt"), ({"D4GS_FWD_WAVE_PER_TILE": "1"}, "/tmp/d4gs_fwd_a.pt")):
+        env = dict(os.environ, **env_extra)
+        subprocess.check_call([sys.executable, "-c", code, name], env=env)
+        outs.append(torch.load(name))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
