@@ -11,6 +11,8 @@
 //     a per-INTERSECTION buffer at the splat's emission index.  Rows of one Gaussian instance are contiguous there,
 //     so k_gather sums them with plain loads in a fixed order -> bitwise reproducible gradients, and no
 //     fabric-level atomic traffic (device-scope float atomics are serialised memory-side on MI355X's 8 XCDs).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -206,6 +208,174 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant B (default): one 256-lane workgroup per tile = 4 waves, each wave owns an 8x8 QUADRANT (1 pixel / lane),
+// batches of 128 splats staged back-to-front once per tile together with their tight alpha >= 1/255 boxes.  Every
+// wave ballots which staged splats (a) touch its quadrant and (b) lie at or before the quadrant's last contributor,
+// and replays only those.  Each wave reduces its row over its 64 lanes (permlane swaps) into its own LDS slab; the
+// four slabs are added in fixed order when the batch is written out - still no atomics, still deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
+#pragma clang fp contract(off)
+  constexpr int NCH = D + (DEPTH ? 1 : 0);
+  constexpr int DP = (D + 3) & ~3;
+  constexpr int DV = DP / 4;
+  constexpr int R = 6 + NCH;
+  constexpr int RP = (R + 1) | 1;
+  constexpr int NB = 128;  // splats per batch
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  __shared__ float4 sg0[NB];
+  __shared__ float4 sg1[NB];
+  __shared__ float4 sbox[NB];
+  __shared__ float4 scol[NB * DV];
+  __shared__ float sgrad[4 * NB * RP];
+  __shared__ int shi[4];
+
+  const int n_tiles_s = a.tw * a.th;
+  const int n_tiles = a.S * n_tiles_s;
+  const int t = a.tile_order ? (blockIdx.x < n_tiles ? a.tile_order[blockIdx.x] : n_tiles) : xcd_remap_b(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
+  if (end <= start) return;
+  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
+  const int ty = tl / a.tw, tx = tl - ty * a.tw;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int qx0 = tx * D4GS_TILE + (wv & 1) * 8, qy0 = ty * D4GS_TILE + (wv >> 1) * 8;
+  const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
+  const bool inside = x < a.width && y < a.height;
+  const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
+  const float qlx = (float)qx0 + 0.5f, qhx = (float)qx0 + 7.5f, qly = (float)qy0 + 0.5f, qhy = (float)qy0 + 7.5f;
+
+  float T = 1.f, va = 0.f, vo[NCH], bsum = 0.f;
+  int last = -1;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) vo[c] = 0.f;
+  if (inside) {
+    const size_t pix = ((size_t)s * a.height + y) * a.width + x;
+    last = a.last_ids[pix];
+    const float al = a.alphas[pix];
+    const float Tfin = 1.f - al;
+    const float *vp = a.v_out + pix * NCH;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) vo[c] = vp[c];
+    float v_al = a.v_alphas ? a.v_alphas[pix] : 0.f;
+    if (DEPTH && a.ed) {
+      const float den = fmaxf(al, 1e-10f);
+      const float vd = vo[D];
+      if (al >= 1e-10f) v_al -= vd * a.out[pix * NCH + D] / den;
+      vo[D] = vd / den;
+    }
+    float bgdot = 0.f;
+    if (a.background) {
+#pragma unroll
+      for (int c = 0; c < D; c++) bgdot += a.background[c] * vo[c];
+    }
+    va = Tfin * (v_al - bgdot);
+    T = Tfin;
+  }
+  // last contributor of this quadrant / of the tile
+  int whi = last < start ? start - 1 : last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) whi = max(whi, __shfl_xor(whi, o));
+  whi = min(whi, end - 1);
+  if (lane == 0) shi[wv] = whi;
+  __syncthreads();
+  const int hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+  const size_t inst_base = (size_t)s * a.N;
+  float *myslab = sgrad + wv * NB * RP;
+
+  for (int bh = hi; bh >= start; bh -= NB) {
+    __syncthreads();
+    int emit = -1;
+    if (tid < NB) {
+      const int idx = bh - tid;
+      if (idx >= start) {
+        const int gid = a.sorted_gid[idx];
+        emit = a.sorted_emit[idx];
+        const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
+        const float4 q0 = gp[0], q1 = gp[1];
+        sg0[tid] = q0;
+        sg1[tid] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, __builtin_amdgcn_rcpf(q0.z));
+        const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
+        const float det = q1.x * q1.z - q1.y * q1.y;
+        const float idet = 1.f / det;
+        float ex = -1.f, ey = -1.f;
+        if (tau > 0.f && det > 0.f) {
+          ex = sqrtf(2.f * tau * q1.z * idet) + 1e-3f;
+          ey = sqrtf(2.f * tau * q1.x * idet) + 1e-3f;
+        }
+        sbox[tid] = ex < 0.f ? make_float4(1e30f, -1e30f, 1e30f, -1e30f)
+                             : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
+        const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
+#pragma unroll
+        for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
+      }
+    }
+    for (int z = tid; z < 4 * NB * RP; z += 256) sgrad[z] = 0.f;
+    __syncthreads();
+    const int nb = min(NB, bh - start + 1);
+#pragma unroll
+    for (int k = 0; k < NB / 64; k++) {
+      const int jj = k * 64 + lane;
+      bool hit = false;
+      if (jj < nb && bh - jj <= whi) {
+        const float4 bx = sbox[jj];
+        hit = (bx.x <= qhx) && (bx.y >= qlx) && (bx.z <= qhy) && (bx.w >= qly);
+      }
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int j = k * 64 + (__ffsll((long long)m) - 1);
+        m &= m - 1;
+        const int cur = bh - j;
+        const float4 g0 = sg0[j], g1 = sg1[j];
+        const float dx = g0.x - pxf, dy = g0.y - pyf;
+        const float sig2 = splat_sigma2(g1, dx, dy);
+        const float ov = g0.z * __builtin_amdgcn_exp2f(-sig2);
+        const float alpha = fminf(0.999f, ov);
+        const bool valid = (cur <= last) && (sig2 >= 0.f) && (alpha >= (1.f / 255.f));
+        if (!__any(valid)) continue;
+        const float am = valid ? alpha : 0.f;
+        const float ra = __builtin_amdgcn_rcpf(1.f - am);
+        T *= ra;
+        const float fac = am * T;
+        float row[R];
+        float d = 0.f;
+#pragma unroll
+        for (int v = 0; v < DV; v++) {
+          const float4 c4 = scol[j * DV + v];
+          if (v * 4 < D) d = __builtin_fmaf(vo[v * 4], c4.x, d);
+          if (v * 4 + 1 < D) d = __builtin_fmaf(vo[v * 4 + 1], c4.y, d);
+          if (v * 4 + 2 < D) d = __builtin_fmaf(vo[v * 4 + 2], c4.z, d);
+          if (v * 4 + 3 < D) d = __builtin_fmaf(vo[v * 4 + 3], c4.w, d);
+        }
+        if (DEPTH) d = __builtin_fmaf(vo[D], g0.w, d);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) row[6 + c] = fac * vo[c];
+        const float v_alpha = __builtin_fmaf(T, d, ra * (va - bsum));
+        bsum = __builtin_fmaf(fac, d, bsum);
+        const bool ok = valid && (ov <= 0.999f);
+        const float vs = ok ? -ov * v_alpha : 0.f;
+        const float vsx = vs * dx, vsy = vs * dy;
+        row[0] = __builtin_fmaf(g1.x, vsx, g1.y * vsy) * LN2;
+        row[1] = __builtin_fmaf(g1.y, vsx, g1.z * vsy) * LN2;
+        row[2] = 0.5f * (vsx * dx);
+        row[3] = vsx * dy;
+        row[4] = 0.5f * (vsy * dy);
+        row[5] = -vs * g1.w;
+        wave_sum_store(row, myslab + j * RP, lane);
+      }
+    }
+    __syncthreads();
+    if (emit >= 0) {
+      float *dst = a.isect_grad + (size_t)emit * R;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        dst[r] = (sgrad[tid * RP + r] + sgrad[(NB + tid) * RP + r]) + (sgrad[(2 * NB + tid) * RP + r] + sgrad[(3 * NB + tid) * RP + r]);
+    }
+  }
+}
+
 // one lane per Gaussian, looping over sub-samples: sums the contiguous per-intersection rows of each instance
 struct GatherArgs {
   int N, S, D, DP, depth;
@@ -261,7 +431,11 @@ int launch_bwd(const RasterBwdArgs &a, const GatherArgs &ga, int64_t n_isect, hi
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
   if (n_isect > 0) {
-    D4GS_LAUNCH("k_raster_bwd", (k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+    static const bool wave_per_tile = getenv("D4GS_BWD_WAVE_PER_TILE") != nullptr;  // variant A, kept for A/B tests
+    if (wave_per_tile)
+      D4GS_LAUNCH("k_raster_bwd", (k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+    else
+      D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
     int rc = d4gs_check_launch("k_raster_bwd");
     if (rc) return rc;
   }
