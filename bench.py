@@ -234,13 +234,14 @@ def main():
             # geom 32 + colours 16 read, gradient row R*4 written; per pixel: v_out 16 + v_alpha 4 + alpha 4 +
             # last_id 4 + out 16 read.
             bytes_bwd = float(proc_bwd.sum().item()) * (4 + 4 + 32 + 16 + R * 4) + S_loc * H * W * 44.0
-            if dom == "k_raster_bwd":
-                flops = pairs_bwd * FLOPS_PER_PAIR_BWD
+            if dom.startswith("k_raster"):
+                flops = pairs_bwd * (FLOPS_PER_PAIR_BWD if "bwd" in dom else FLOPS_PER_PAIR_FWD)
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": flops / t_k / 1e12,
                                    "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS,
                                    "traffic": None, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
-                                   "note": "fp32 VALU-bound composite adjoint; fp32 vector peak == fp32-input dense MFMA "
-                                           "peak (157.3 TFLOP/s, MI355X_MICROARCH.md); no MFMA is issued"}
+                                   "note": "fp32 VALU-bound composite; algorithmic ops of the reference per (splat, pixel) "
+                                           "of each 16x16 tile x pairs replayed; fp32 vector peak == fp32-input dense "
+                                           "MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); no MFMA is issued"}
                 out["roofline_hbm"] = {"kernel": dom, "bound": "hbm", "achieved": bytes_bwd / t_k / 1e9,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_bwd / t_k / 1e9 / HBM_PEAK_GBS,
                                        "traffic": None}
