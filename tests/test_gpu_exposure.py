@@ -23,7 +23,10 @@ def _split(sc, dtype):
 @pytest.mark.parametrize("N,G,K,S,W,H,mask,depth", [(1500, 900, 4, 3, 96, 64, True, True),
                                                     (1200, 1200, 6, 4, 80, 48, False, True),
                                                     (900, 300, 2, 1, 64, 64, True, False),
-                                                    (1000, 600, 5, 2, 72, 40, False, False)])
+                                                    (1000, 600, 5, 2, 72, 40, False, False),
+                                                    # the reference's defaults: 20 bases, 11 sub-samples
+                                                    (700, 300, 20, 11, 64, 48, True, True),
+                                                    (500, 500, 32, 16, 48, 48, False, True)])
 def test_exposure_forward_backward(N, G, K, S, W, H, mask, depth):
     from deblur4dgs_amd.exposure import render_exposure
 

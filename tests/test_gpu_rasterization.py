@@ -209,3 +209,50 @@ torch.save((rc.cpu(), ra.cpu(), info["last_ids"].cpu()), sys.argv[1])
         outs.append(torch.load(name))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("scale_mul,radius_clip,near,far", [(40.0, 0.0, 0.01, 1e10), (3.0, 4.0, 0.01, 1e10),
+                                                            (3.0, 0.0, 4.0, 8.0)])
+def test_big_splats_and_cull_parameters(scale_mul, radius_clip, near, far):
+    """Splats spanning many tiles (every tile list long, rects clipped at the image border) and the three cull
+    knobs gsplat exposes (radius_clip, near_plane, far_plane), forward + backward."""
+    from deblur4dgs_amd.rasterization import rasterization
+
+    W, H, N = 112, 72, 400
+    inp = static_inputs(N, W, H, seed=31, dtype=torch.float64, scale_mul=scale_mul)
+    t = {k: v.clone().requires_grad_(k != "K") for k, v in inp.items()}
+    ref_c, ref_a, ref_info = raster.rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"],
+                                                  t["K"], W, H, background=torch.ones(3, dtype=torch.float64),
+                                                  render_mode="RGB+ED", radius_clip=radius_clip, near_plane=near,
+                                                  far_plane=far)
+    (ref_c.sum() + ref_a.sum()).backward()
+    dev = torch.device("cuda:0")
+    g = {k: v.detach().float().to(dev).requires_grad_(k != "K") for k, v in inp.items()}
+    rc, ra, info = rasterization(g["means"], g["quats"], g["scales"], g["opac"], g["colors"], g["V"][None], g["K"][None],
+                                 W, H, backgrounds=torch.ones(1, 3, device=dev), render_mode="RGB+ED",
+                                 radius_clip=radius_clip, near_plane=near, far_plane=far)
+    (rc.sum() + ra.sum()).backward()
+    torch.cuda.synchronize()
+    assert ((info["radii"][0].cpu() > 0) != (ref_info["radii"] > 0)).float().mean() < 5e-3
+    assert frac_bad(rc[0].cpu(), ref_c, 1e-4) < 3e-3, rel_err(rc[0].cpu(), ref_c)
+    for name in ("means", "scales", "opac", "colors"):
+        assert frac_bad(g[name].grad.cpu(), t[name].grad, 2e-3) < 5e-3, (name, rel_err(g[name].grad.cpu(), t[name].grad))
+
+
+def test_single_gaussian_and_api_errors():
+    from deblur4dgs_amd.rasterization import rasterization
+
+    dev = torch.device("cuda:0")
+    K = torch.tensor([[[40.0, 0, 20], [0, 40.0, 12], [0, 0, 1]]], device=dev)
+    rc, ra, info = rasterization(torch.tensor([[0.0, 0.0, 3.0]], device=dev), torch.tensor([[1.0, 0, 0, 0]], device=dev),
+                                 torch.full((1, 3), 0.3, device=dev), torch.tensor([0.8], device=dev),
+                                 torch.tensor([[0.1, 0.2, 0.3]], device=dev), torch.eye(4, device=dev)[None], K, 40, 24)
+    torch.cuda.synchronize()
+    assert rc.shape == (1, 24, 40, 3) and ra.max() > 0.5 and info["n_isect"] >= 1
+    with pytest.raises(ValueError):
+        rasterization(torch.zeros(1, 3, device=dev), torch.zeros(1, 4, device=dev), torch.ones(1, 3, device=dev),
+                      torch.ones(1, device=dev), torch.ones(1, 3, device=dev), torch.eye(4, device=dev).repeat(2, 1, 1),
+                      K.repeat(2, 1, 1), 40, 24)  # C must be 1
+    with pytest.raises(RuntimeError):  # CPU tensors: no fallback
+        rasterization(torch.zeros(1, 3), torch.zeros(1, 4), torch.ones(1, 3), torch.ones(1), torch.ones(1, 3),
+                      torch.eye(4)[None], K.cpu(), 40, 24)
