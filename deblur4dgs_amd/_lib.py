@@ -30,7 +30,7 @@ class ProjIn(C.Structure):
 
 class ProjOut(C.Structure):
     _fields_ = [(n, F) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects", "tiles_touched",
-                                 "isect_offsets", "tile_counts", "tile_offsets", "n_isect", "scan_ws")]
+                                 "isect_offsets", "tile_ranks", "tile_counts", "tile_offsets", "n_isect", "scan_ws")]
 
 
 class Isect(C.Structure):

@@ -17,9 +17,10 @@ struct EmitArgs {
   D4gsDims d;
   const float *geom;
   const int32_t *tile_rects;
+  const int32_t *tile_ranks;
   const int32_t *tiles_touched;
   const int32_t *isect_offsets;
-  int32_t *tile_cursor;  // tile_counts, counted down to 0
+  int32_t *tile_cursor;  // tile_counts: [0,T) counts of the rank-carrying splats, [T,2T) cursors of the wide ones
   const int32_t *tile_offsets;
   uint64_t *keys;
   int32_t *gid_of_emit;
@@ -44,10 +45,29 @@ __global__ void __launch_bounds__(256) k_emit(const EmitArgs a) {
   const uint64_t hi = (uint64_t)__float_as_uint(g0.w) << 32;
   uint32_t e = (uint32_t)a.isect_offsets[i];
   const int tbase = s * a.tw * a.th;
+  const int n_tiles_all = a.d.S * a.tw * a.th;
+  if (cnt <= D4GS_RANK_SLOTS) {  // ranks came out of the counting pass: no atomics here
+    const int4 *rp = reinterpret_cast<const int4 *>(a.tile_ranks + i * D4GS_RANK_SLOTS);
+    const int4 rk = rp[0];
+    int4 rk2 = make_int4(0, 0, 0, 0);
+    if (cnt > 4) rk2 = rp[1];
+    const int r[8] = {rk.x, rk.y, rk.z, rk.w, rk2.x, rk2.y, rk2.z, rk2.w};
+    const int w = x1 - x0;
+#pragma unroll
+    for (int k = 0; k < D4GS_RANK_SLOTS; k++)
+      if (k < cnt) {
+        const int t = tbase + (y0 + k / w) * a.tw + x0 + k % w;
+        const int slot = a.tile_offsets[t] + r[k];
+        a.keys[slot] = hi | (e + k);
+        a.gid_of_emit[e + k] = g;
+      }
+    return;
+  }
   for (int ty = y0; ty < y1; ty++)
     for (int tx = x0; tx < x1; tx++) {
       const int t = tbase + ty * a.tw + tx;
-      const int slot = a.tile_offsets[t] + atomicSub(a.tile_cursor + t, 1) - 1;
+      // wide splats sit behind the rank-carrying ones in the (unsorted) tile segment
+      const int slot = a.tile_offsets[t] + a.tile_cursor[t] + atomicSub(a.tile_cursor + n_tiles_all + t, 1) - 1;
       a.keys[slot] = hi | e;
       a.gid_of_emit[e] = g;
       e++;
@@ -125,6 +145,7 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.d = *dims;
   e.geom = proj->geom;
   e.tile_rects = proj->tile_rects;
+  e.tile_ranks = proj->tile_ranks;
   e.tiles_touched = proj->tiles_touched;
   e.isect_offsets = proj->isect_offsets;
   e.tile_cursor = proj->tile_counts;

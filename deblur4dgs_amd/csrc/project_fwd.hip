@@ -161,9 +161,25 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       if (d.flags & D4GS_EXACT_CULL) tight_rect(m2x, m2y, opac, p.a, p.c, x0, y0, x1, y1);
       rect = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       cnt = (x1 - x0) * (y1 - y0);
+      const int n_tiles_all = S * a.tw * a.th;
       int *tc = a.out.tile_counts + (size_t)s * a.tw * a.th;
-      for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) atomicAdd(tc + ty * a.tw + tx, 1);
+      if (cnt <= D4GS_RANK_SLOTS) {
+        // common case: the RETURNING atomic is both the count and this splat's rank inside the tile list, so the
+        // emit pass needs no atomics at all for it (up to 8 independent atomics in flight, one wait)
+        const int w = x1 - x0;
+        int r[D4GS_RANK_SLOTS];
+#pragma unroll
+        for (int k = 0; k < D4GS_RANK_SLOTS; k++) {
+          r[k] = 0;
+          if (k < cnt) r[k] = atomicAdd(tc + (y0 + k / w) * a.tw + x0 + k % w, 1);
+        }
+        int4 *rp = reinterpret_cast<int4 *>(a.out.tile_ranks + i * D4GS_RANK_SLOTS);
+        rp[0] = make_int4(r[0], r[1], r[2], r[3]);
+        if (cnt > 4) rp[1] = make_int4(r[4], r[5], r[6], r[7]);
+      } else {  // wide splats: counted apart (second half of tile_counts), ranked by k_emit
+        for (int ty = y0; ty < y1; ty++)
+          for (int tx = x0; tx < x1; tx++) atomicAdd(tc + n_tiles_all + ty * a.tw + tx, 1);
+      }
     }
     a.out.radii[i] = p.radius;
     *reinterpret_cast<float2 *>(a.out.means2d + i * 2) = make_float2(m2x, m2y);
@@ -221,13 +237,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(const int *in, int64
 
 // single block: exclusive scan of `n` ints in place (looping with a carry); optionally writes the total to
 // out[n] (int32) and to total64.
-__global__ void __launch_bounds__(1024) k_scan_single(const int *in, int *out, int64_t n, int write_last,
+__global__ void __launch_bounds__(1024) k_scan_single(const int *in, const int *in2, int *out, int64_t n, int write_last,
                                                        int64_t *total64) {
   __shared__ int lds[20];
   int64_t carry = 0;
   for (int64_t base = 0; base < n; base += blockDim.x) {
     int64_t i = base + threadIdx.x;
-    int v = i < n ? in[i] : 0;
+    int v = i < n ? in[i] + (in2 ? in2[i] : 0) : 0;
     int tot;
     int ex = block_exclusive_scan(v, &tot, lds);
     if (i < n) out[i] = (int)(carry + ex);
@@ -295,7 +311,7 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   const int64_t n_inst = (int64_t)dims->S * dims->N;
   const int64_t n_tiles = (int64_t)dims->S * a.tw * a.th;
-  hipError_t e = hipMemsetAsync(out->tile_counts, 0, sizeof(int32_t) * n_tiles, stream);
+  hipError_t e = hipMemsetAsync(out->tile_counts, 0, sizeof(int32_t) * 2 * n_tiles, stream);
   if (e != hipSuccess) {
     d4gs_set_error("hipMemsetAsync(tile_counts): %s", hipGetErrorString(e));
     return D4GS_ELAUNCH;
@@ -314,11 +330,11 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   const int sblocks = (int)((n_inst + SCAN_TILE - 1) / SCAN_TILE);
   D4GS_LAUNCH("k_scan_sums", k_scan_sums, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, n_inst,
                      out->scan_ws);
-  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->scan_ws, out->scan_ws, (int64_t)sblocks, 0,
+  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->scan_ws, (const int *)nullptr, out->scan_ws, (int64_t)sblocks, 0,
                      out->n_isect);
   D4GS_LAUNCH("k_scan_apply", k_scan_apply, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, out->scan_ws,
                      n_inst, out->isect_offsets);
-  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->tile_counts, out->tile_offsets, n_tiles, 1,
+  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->tile_counts, (const int *)(out->tile_counts + n_tiles), out->tile_offsets, n_tiles, 1,
                      (int64_t *)nullptr);
   return d4gs_check_launch("scan");
 }
