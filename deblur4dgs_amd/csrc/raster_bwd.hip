@@ -284,6 +284,12 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   const int hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
   const size_t inst_base = (size_t)s * a.N;
   float *myslab = sgrad + wv * NB * RP;
+  // rows behind the tile's last contributor are never replayed: zero them here (no whole-buffer memset needed)
+  for (int idx = hi + 1 + tid; idx < end; idx += 256) {
+    float *dst = a.isect_grad + (size_t)a.sorted_emit[idx] * R;
+#pragma unroll
+    for (int r = 0; r < R; r++) dst[r] = 0.f;
+  }
 
   for (int bh = hi; bh >= start; bh -= NB) {
     __syncthreads();
@@ -413,7 +419,7 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs a) {
     vo += acc[5];
 #pragma unroll
     for (int c = 0; c < D; c++) vc[c] += acc[6 + c];
-    if (DEPTH) a.v_depths[i] = acc[6 + D];
+    a.v_depths[i] = DEPTH ? acc[6 + (DEPTH ? D : 0)] : 0.f;
   }
   a.v_opac_act[g] = vo;
 #pragma unroll
@@ -423,15 +429,17 @@ __global__ void __launch_bounds__(256) k_gather(const GatherArgs a) {
 template <int D, bool DEPTH>
 int launch_bwd(const RasterBwdArgs &a, const GatherArgs &ga, int64_t n_isect, hipStream_t stream) {
   constexpr int R = 6 + D + (DEPTH ? 1 : 0);
-  hipError_t e = hipMemsetAsync(a.isect_grad, 0, sizeof(float) * (size_t)R * (size_t)(n_isect > 0 ? n_isect : 1), stream);
-  if (e != hipSuccess) {
-    d4gs_set_error("hipMemsetAsync(isect_grad): %s", hipGetErrorString(e));
-    return D4GS_ELAUNCH;
+  static const bool wave_per_tile = getenv("D4GS_BWD_WAVE_PER_TILE") != nullptr;  // variant A, kept for A/B tests
+  if (wave_per_tile) {  // variant A relies on a zeroed buffer; variant B zero-fills what it does not replay itself
+    hipError_t e = hipMemsetAsync(a.isect_grad, 0, sizeof(float) * (size_t)R * (size_t)(n_isect > 0 ? n_isect : 1), stream);
+    if (e != hipSuccess) {
+      d4gs_set_error("hipMemsetAsync(isect_grad): %s", hipGetErrorString(e));
+      return D4GS_ELAUNCH;
+    }
   }
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
   if (n_isect > 0) {
-    static const bool wave_per_tile = getenv("D4GS_BWD_WAVE_PER_TILE") != nullptr;  // variant A, kept for A/B tests
     if (wave_per_tile)
       D4GS_LAUNCH("k_raster_bwd", (k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
     else

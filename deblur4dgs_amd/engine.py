@@ -214,7 +214,7 @@ class RasterFn(torch.autograd.Function):
             v_render_colors=v_colors, v_render_alphas=v_alphas,
             isect_grad=torch.empty(max(st.n_isect, 1), 6 + cfg.NCH, **f32),
             v_means2d=torch.empty(S, N, 2, **f32), v_conics=torch.empty(S, N, 3, **f32),
-            v_depths=torch.zeros(S, N, **f32), v_opac_act=torch.empty(N, **f32), v_ctab=torch.empty(N, cfg.DP, **f32),
+            v_depths=torch.empty(S, N, **f32), v_opac_act=torch.empty(N, **f32), v_ctab=torch.empty(N, cfg.DP, **f32),
         )
         dims = cfg.dims()
         _, pout = _proj_structs(st)

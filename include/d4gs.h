@@ -122,10 +122,10 @@ typedef struct D4gsRaster {
 typedef struct D4gsRasterGrads {
   const float *v_render_colors; /* [S,H,W,D+depth] */
   const float *v_render_alphas; /* [S,H,W] or NULL */
-  float *isect_grad;            /* [n_isect, 6+D+depth] scratch (zero-filled by the call) */
+  float *isect_grad;            /* [n_isect, 6+D+depth] scratch (every row is written by the call) */
   float *v_means2d;             /* [S,N,2]  (= means2d.grad contract, trainer.py:975) */
   float *v_conics;              /* [S,N,3] */
-  float *v_depths;              /* [S,N]   (only written when depth_mode != 0) */
+  float *v_depths;              /* [S,N]   (zeros when depth_mode == 0) */
   float *v_opac_act;            /* [N]     summed over S */
   float *v_ctab;                /* [N,DP]  summed over S */
 } D4gsRasterGrads;
