@@ -234,17 +234,28 @@ def main():
             # geom 32 + colours 16 read, gradient row R*4 written; per pixel: v_out 16 + v_alpha 4 + alpha 4 +
             # last_id 4 + out 16 read.
             bytes_bwd = float(proc_bwd.sum().item()) * (4 + 4 + 32 + 16 + R * 4) + S_loc * H * W * 44.0
+            traffic = None
+            try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (MI355X_MICROARCH.md, HBM section)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[name]["kernels"][dom]
+                if args.channels == 3:
+                    traffic = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+            except Exception:
+                traffic = None
             if dom.startswith("k_raster"):
                 flops = pairs_bwd * (FLOPS_PER_PAIR_BWD if "bwd" in dom else FLOPS_PER_PAIR_FWD)
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": flops / t_k / 1e12,
                                    "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS,
-                                   "traffic": None, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
+                                   "traffic": traffic, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
+                                   "traffic_note": "FETCH_SIZE + WRITE_SIZE (KB) x 1024 from separate rocprofv3 --pmc passes "
+                                                   "(profiles/pmc_traffic.json); gfx950's FETCH_SIZE can under-count wide "
+                                                   "coalesced reads 2x, so true read traffic lies between 1x and 2x the "
+                                                   "fetch term",
                                    "note": "fp32 VALU-bound composite; algorithmic ops of the reference per (splat, pixel) "
                                            "of each 16x16 tile x pairs replayed; fp32 vector peak == fp32-input dense "
                                            "MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); no MFMA is issued"}
                 out["roofline_hbm"] = {"kernel": dom, "bound": "hbm", "achieved": bytes_bwd / t_k / 1e9,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_bwd / t_k / 1e9 / HBM_PEAK_GBS,
-                                       "traffic": None}
+                                       "traffic": traffic, "algorithmic_bytes": bytes_bwd}
             else:
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": t_k * 1e3}
