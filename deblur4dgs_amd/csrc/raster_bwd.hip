@@ -382,6 +382,266 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant C: variant B's mapping, but the per-splat reductions over the quadrant's 64 pixels run on the MATRIX pipe.
+// Every gradient of a splat is a pixel-sum of one of two per-(pixel, splat) scalars times a per-pixel constant:
+//     vs  = dL/dsigma      ->  moments  S_q[j] = sum_p W[q][p] vs[p][j],  W = {1, x, y, x^2, xy, y^2} (quadrant-relative)
+//     fac = alpha * T      ->  colours  V_c[j] = sum_p vo[c][p] fac[p][j]
+// i.e. two GEMMs with K = 64 pixels, A fixed per wave (W is the same for every wave; vo is the quadrant's image
+// gradient) and B produced during the replay.  Lanes write vs / fac to a transposed LDS tile; every 16 valid splats
+// the wave issues 16 + 16 v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fma chain -> deterministic) and 16 lanes turn
+// the 6 moments into d/dx, d/dy, d/dconic, d/dopacity.  This removes the ~45 % of VALU time variant B spends in
+// cross-lane reductions, and the MFMA pipe runs beside the VALU pipe of the SIMD's other waves.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
+#pragma clang fp contract(off)
+  constexpr int NCH = D + (DEPTH ? 1 : 0);
+  constexpr int DP = (D + 3) & ~3;
+  constexpr int DV = DP / 4;
+  constexpr int R = 6 + NCH;
+  constexpr int RP = (R + 1) | 1;
+  constexpr int NB = 64;              // splats per batch
+  constexpr int HF = 8;               // valid splats per MFMA flush (half of the 16 columns of a 16x16x4 tile: LDS budget)
+  constexpr int TS = 66;              // transposed-tile row stride (floats): conflict-free B-fragment reads
+  constexpr int CB = (NCH + 15) / 16; // 16-row colour blocks
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  __shared__ float4 sg0[NB];
+  __shared__ float4 sg1[NB];
+  __shared__ float4 sbox[NB];
+  __shared__ float4 scol[NB * DV];
+  __shared__ float sgrad[4 * NB * RP];
+  constexpr int STRN = (4 * 2 * HF * TS > 256 * NCH) ? 4 * 2 * HF * TS : 256 * NCH;
+  __shared__ float strn[STRN];              // per wave: vsT[HF][TS], facT[HF][TS]; first used to pass the tile's image
+  float *svo = strn;                        // gradient between lanes (A-operand source) before the replay starts
+  __shared__ int shit[4 * HF];
+  __shared__ int shi[4];
+
+  const int n_tiles_s = a.tw * a.th;
+  const int n_tiles = a.S * n_tiles_s;
+  const int t = a.tile_order ? (blockIdx.x < n_tiles ? a.tile_order[blockIdx.x] : n_tiles) : xcd_remap_b(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
+  if (end <= start) return;
+  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
+  const int ty = tl / a.tw, tx = tl - ty * a.tw;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int qx0 = tx * D4GS_TILE + (wv & 1) * 8, qy0 = ty * D4GS_TILE + (wv >> 1) * 8;
+  const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
+  const bool inside = x < a.width && y < a.height;
+  const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
+  const float qlx = (float)qx0 + 0.5f, qhx = (float)qx0 + 7.5f, qly = (float)qy0 + 0.5f, qhy = (float)qy0 + 7.5f;
+  const float qcx = (float)qx0 + 4.f, qcy = (float)qy0 + 4.f;  // quadrant centre (pixel-centre coordinates)
+
+  float T = 1.f, va = 0.f, vo[NCH], bsum = 0.f;
+  int last = -1;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) vo[c] = 0.f;
+  if (inside) {
+    const size_t pix = ((size_t)s * a.height + y) * a.width + x;
+    last = a.last_ids[pix];
+    const float al = a.alphas[pix];
+    const float Tfin = 1.f - al;
+    const float *vp = a.v_out + pix * NCH;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) vo[c] = vp[c];
+    float v_al = a.v_alphas ? a.v_alphas[pix] : 0.f;
+    if (DEPTH && a.ed) {
+      const float den = fmaxf(al, 1e-10f);
+      const float vd = vo[D];
+      if (al >= 1e-10f) v_al -= vd * a.out[pix * NCH + D] / den;
+      vo[D] = vd / den;
+    }
+    float bgdot = 0.f;
+    if (a.background) {
+#pragma unroll
+      for (int c = 0; c < D; c++) bgdot += a.background[c] * vo[c];
+    }
+    va = Tfin * (v_al - bgdot);
+    T = Tfin;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; c++) svo[tid * NCH + c] = vo[c];
+  int whi = last < start ? start - 1 : last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) whi = max(whi, __shfl_xor(whi, o));
+  whi = min(whi, end - 1);
+  if (lane == 0) shi[wv] = whi;
+  __syncthreads();
+  const int hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+
+  // A fragments (v_mfma_f32_16x16x4_f32: lane l holds A[row = l & 15][k = l >> 4]); k-step kk covers pixels 4kk..4kk+3
+  float a1[16], a2[CB][16];
+  {
+    const int row = lane & 15;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+      const int p = 4 * kk + (lane >> 4);
+      const float xr = (float)(p & 7) - 3.5f, yr = (float)(p >> 3) - 3.5f;
+      a1[kk] = row == 0 ? 1.f : row == 1 ? xr : row == 2 ? yr : row == 3 ? xr * xr : row == 4 ? xr * yr : row == 5 ? yr * yr : 0.f;
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++) {
+        const int ch = cb * 16 + row;
+        a2[cb][kk] = ch < NCH ? svo[(wv * 64 + p) * NCH + ch] : 0.f;
+      }
+    }
+  }
+  const size_t inst_base = (size_t)s * a.N;
+  float *myslab = sgrad + wv * NB * RP;
+  float *vsT = strn + wv * 2 * HF * TS, *facT = vsT + HF * TS;
+  int *myhit = shit + wv * HF;
+  for (int idx = hi + 1 + tid; idx < end; idx += 256) {
+    float *dst = a.isect_grad + (size_t)a.sorted_emit[idx] * R;
+#pragma unroll
+    for (int r = 0; r < R; r++) dst[r] = 0.f;
+  }
+
+  // turn the accumulated tile (nh valid splats) into gradient rows in this wave's slab
+  auto flush = [&](int nh) {
+    // two accumulators per chain (even / odd k-steps): the dependent-accumulator latency (40 cyc) exceeds the issue
+    // interval (32 cyc); the halves are added in fixed order afterwards
+    f32x4 accm = {0.f, 0.f, 0.f, 0.f}, accm1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accc[CB], accc1[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) accc[cb] = f32x4{0.f, 0.f, 0.f, 0.f}, accc1[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int boff = (lane & 15) < HF ? (lane & 15) * TS + (lane >> 4) : (lane >> 4);  // columns >= HF: any finite data
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      const float bv = vsT[boff + 4 * kk], bf = facT[boff + 4 * kk];
+      const float bv1 = vsT[boff + 4 * kk + 4], bf1 = facT[boff + 4 * kk + 4];
+      accm = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kk], bv, accm, 0, 0, 0);
+      accm1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kk + 1], bv1, accm1, 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++) {
+        accc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[cb][kk], bf, accc[cb], 0, 0, 0);
+        accc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[cb][kk + 1], bf1, accc1[cb], 0, 0, 0);
+      }
+    }
+    accm += accm1;
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) accc[cb] += accc1[cb];
+    // C/D layout: col (valid splat n) = lane & 15, row = (lane >> 4) * 4 + reg.  Park the tile in LDS (vsT is free now)
+    float *scr = vsT;  // [HF][24 + ...]: moments 0..5, then colours
+    constexpr int SW = 8 + 16 * CB;
+    const int n = lane & 15, r0 = (lane >> 4) * 4;
+    if (n < HF) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (r0 + i < 6) scr[n * SW + r0 + i] = accm[i];
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+          if (cb * 16 + r0 + i < NCH) scr[n * SW + 8 + cb * 16 + r0 + i] = accc[cb][i];
+      }
+    }
+    if (lane < nh) {
+      const int j = myhit[lane];
+      const float4 g0 = sg0[j], g1 = sg1[j];
+      const float *m = scr + lane * SW;
+      const float S0 = m[0], Sx = m[1], Sy = m[2], Sxx = m[3], Sxy = m[4], Syy = m[5];
+      const float mx = g0.x - qcx, my = g0.y - qcy;
+      const float Dx = mx * S0 - Sx, Dy = my * S0 - Sy;
+      const float Dxx = mx * (mx * S0 - 2.f * Sx) + Sxx;
+      const float Dxy = mx * (my * S0 - Sy) - my * Sx + Sxy;
+      const float Dyy = my * (my * S0 - 2.f * Sy) + Syy;
+      float *dst = myslab + j * RP;
+      dst[0] = (g1.x * Dx + g1.y * Dy) * LN2;
+      dst[1] = (g1.y * Dx + g1.z * Dy) * LN2;
+      dst[2] = 0.5f * Dxx;
+      dst[3] = Dxy;
+      dst[4] = 0.5f * Dyy;
+      dst[5] = -S0 * g1.w;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) dst[6 + c] = m[8 + c];
+    }
+  };
+
+  for (int bh = hi; bh >= start; bh -= NB) {
+    __syncthreads();
+    int emit = -1;
+    if (tid < NB) {
+      const int idx = bh - tid;
+      if (idx >= start) {
+        const int gid = a.sorted_gid[idx];
+        emit = a.sorted_emit[idx];
+        const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
+        const float4 q0 = gp[0], q1 = gp[1];
+        sg0[tid] = q0;
+        sg1[tid] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, __builtin_amdgcn_rcpf(q0.z));
+        const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
+        const float det = q1.x * q1.z - q1.y * q1.y;
+        const float idet = 1.f / det;
+        float ex = -1.f, ey = -1.f;
+        if (tau > 0.f && det > 0.f) {
+          ex = sqrtf(2.f * tau * q1.z * idet) + 1e-3f;
+          ey = sqrtf(2.f * tau * q1.x * idet) + 1e-3f;
+        }
+        sbox[tid] = ex < 0.f ? make_float4(1e30f, -1e30f, 1e30f, -1e30f)
+                             : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
+        const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
+#pragma unroll
+        for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
+      }
+    }
+    for (int z = tid; z < 4 * NB * RP; z += 256) sgrad[z] = 0.f;
+    __syncthreads();
+    const int nb = min(NB, bh - start + 1);
+    bool hit = false;
+    if (lane < nb && bh - lane <= whi) {
+      const float4 bx = sbox[lane];
+      hit = (bx.x <= qhx) && (bx.y >= qlx) && (bx.z <= qhy) && (bx.w >= qly);
+    }
+    unsigned long long msk = __ballot(hit);
+    int nh = 0;
+    while (msk) {
+      const int j = __ffsll((long long)msk) - 1;
+      msk &= msk - 1;
+      const int cur = bh - j;
+      const float4 g0 = sg0[j], g1 = sg1[j];
+      const float dx = g0.x - pxf, dy = g0.y - pyf;
+      const float sig2 = splat_sigma2(g1, dx, dy);
+      const float ov = g0.z * __builtin_amdgcn_exp2f(-sig2);
+      const float alpha = fminf(0.999f, ov);
+      const bool valid = (cur <= last) && (sig2 >= 0.f) && (alpha >= (1.f / 255.f));
+      if (!__any(valid)) continue;
+      const float am = valid ? alpha : 0.f;
+      const float ra = __builtin_amdgcn_rcpf(1.f - am);
+      T *= ra;
+      const float fac = am * T;
+      float d = 0.f;
+#pragma unroll
+      for (int v = 0; v < DV; v++) {
+        const float4 c4 = scol[j * DV + v];
+        if (v * 4 < D) d = __builtin_fmaf(vo[v * 4], c4.x, d);
+        if (v * 4 + 1 < D) d = __builtin_fmaf(vo[v * 4 + 1], c4.y, d);
+        if (v * 4 + 2 < D) d = __builtin_fmaf(vo[v * 4 + 2], c4.z, d);
+        if (v * 4 + 3 < D) d = __builtin_fmaf(vo[v * 4 + 3], c4.w, d);
+      }
+      if (DEPTH) d = __builtin_fmaf(vo[D], g0.w, d);
+      const float v_alpha = __builtin_fmaf(T, d, ra * (va - bsum));
+      bsum = __builtin_fmaf(fac, d, bsum);
+      const bool ok = valid && (ov <= 0.999f);
+      const float vs = ok ? -ov * v_alpha : 0.f;
+      vsT[nh * TS + lane] = vs;
+      facT[nh * TS + lane] = fac;
+      if (lane == 0) myhit[nh] = j;
+      if (++nh == HF) {
+        flush(HF);
+        nh = 0;
+      }
+    }
+    if (nh) flush(nh);
+    __syncthreads();
+    if (emit >= 0) {
+      float *dst = a.isect_grad + (size_t)emit * R;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        dst[r] = (sgrad[tid * RP + r] + sgrad[(NB + tid) * RP + r]) + (sgrad[(2 * NB + tid) * RP + r] + sgrad[(3 * NB + tid) * RP + r]);
+    }
+  }
+}
+
 // one lane per Gaussian, looping over sub-samples: sums the contiguous per-intersection rows of each instance
 struct GatherArgs {
   int N, S, D, DP, depth;
@@ -440,8 +700,13 @@ int launch_bwd(const RasterBwdArgs &a, const GatherArgs &ga, int64_t n_isect, hi
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
   if (n_isect > 0) {
+    // variant C (reductions on the matrix pipe) is opt-in: measured on MI355X it is slower than B at 4 channels
+    // (1.04-1.24 vs 0.81 ms on cfg2) and only ~5 % faster at 17 (2.06 vs 2.16 ms) - see DESIGN.md section 4
+    static const bool use_mfma = getenv("D4GS_BWD_MFMA") != nullptr;
     if (wave_per_tile)
       D4GS_LAUNCH("k_raster_bwd", (k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+    else if (use_mfma)
+      D4GS_LAUNCH("k_raster_bwd_m", (k_raster_bwd_m<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
     else
       D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
     int rc = d4gs_check_launch("k_raster_bwd");
