@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   constexpr int DV = DP / 4;
   constexpr int R = 6 + NCH;
   constexpr int RP = (R + 1) | 1;
-  constexpr int NB = 128;  // splats per batch
+  constexpr int NB = 64;  // splats per batch
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   __shared__ float4 sg0[NB];
   __shared__ float4 sg1[NB];
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
     __syncthreads();
     const int nb = min(NB, bh - start + 1);
 #pragma unroll
-    for (int k = 0; k < NB / 64; k++) {
+    for (int k = 0; k < (NB + 63) / 64; k++) {
       const int jj = k * 64 + lane;
       bool hit = false;
       if (jj < nb && bh - jj <= whi) {

@@ -151,10 +151,11 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
   constexpr int DP = (D + 3) & ~3;
   constexpr int DV = DP / 4;
   constexpr float LOG2E = 1.4426950408889634f;
-  __shared__ float4 sg0[256];
-  __shared__ float4 sg1[256];
-  __shared__ float4 sbox[256];
-  __shared__ float4 scol[256 * DV];
+  constexpr int FB = 256;  // splats per batch (forward)
+  __shared__ float4 sg0[FB];
+  __shared__ float4 sg1[FB];
+  __shared__ float4 sbox[FB];
+  __shared__ float4 scol[FB * DV];
 
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
@@ -178,10 +179,10 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
 
   const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   const size_t inst_base = (size_t)s * a.N;
-  for (int b = start; b < end; b += 256) {
+  for (int b = start; b < end; b += FB) {
     if (__syncthreads_and(done)) break;  // also orders the previous batch's LDS reads before restaging
     const int idx = b + tid;
-    if (idx < end) {
+    if (tid < FB && idx < end) {
       const int gid = a.sorted_gid[idx];
       const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
       const float4 q0 = gp[0], q1 = gp[1];
@@ -202,10 +203,10 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
       for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
     }
     __syncthreads();
-    const int nb = min(256, end - b);
-    unsigned long long mask[4];
+    const int nb = min(FB, end - b);
+    unsigned long long mask[FB / 64];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < FB / 64; k++) {
       const int j = k * 64 + lane;
       bool hit = false;
       if (j < nb) {
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
     bool wdone = false;
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < FB / 64; k++) {
       unsigned long long m = wdone ? 0ull : mask[k];
       while (m) {
         const int j = k * 64 + (__ffsll((long long)m) - 1);
