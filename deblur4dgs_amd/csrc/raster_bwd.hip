@@ -362,22 +362,33 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         bsum = __builtin_fmaf(fac, d, bsum);
         const bool ok = valid && (ov <= 0.999f);
         const float vs = ok ? -ov * v_alpha : 0.f;
+        // raw pixel sums only; the per-splat linear map (conic, ln2, 1/2, 1/opacity) is applied once at write-out
         const float vsx = vs * dx, vsy = vs * dy;
-        row[0] = __builtin_fmaf(g1.x, vsx, g1.y * vsy) * LN2;
-        row[1] = __builtin_fmaf(g1.y, vsx, g1.z * vsy) * LN2;
-        row[2] = 0.5f * (vsx * dx);
+        row[0] = vsx;
+        row[1] = vsy;
+        row[2] = vsx * dx;
         row[3] = vsx * dy;
-        row[4] = 0.5f * (vsy * dy);
-        row[5] = -vs * g1.w;
+        row[4] = vsy * dy;
+        row[5] = vs;
         wave_sum_store(row, myslab + j * RP, lane);
       }
     }
     __syncthreads();
     if (emit >= 0) {
-      float *dst = a.isect_grad + (size_t)emit * R;
+      float sum[R];
 #pragma unroll
       for (int r = 0; r < R; r++)
-        dst[r] = (sgrad[tid * RP + r] + sgrad[(NB + tid) * RP + r]) + (sgrad[(2 * NB + tid) * RP + r] + sgrad[(3 * NB + tid) * RP + r]);
+        sum[r] = (sgrad[tid * RP + r] + sgrad[(NB + tid) * RP + r]) + (sgrad[(2 * NB + tid) * RP + r] + sgrad[(3 * NB + tid) * RP + r]);
+      const float4 g1 = sg1[tid];  // conic * log2(e), 1 / opacity
+      float *dst = a.isect_grad + (size_t)emit * R;
+      dst[0] = (g1.x * sum[0] + g1.y * sum[1]) * LN2;  // dL/dx = a Sum(vs dx) + b Sum(vs dy)
+      dst[1] = (g1.y * sum[0] + g1.z * sum[1]) * LN2;
+      dst[2] = 0.5f * sum[2];
+      dst[3] = sum[3];
+      dst[4] = 0.5f * sum[4];
+      dst[5] = -sum[5] * g1.w;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) dst[6 + c] = sum[6 + c];
     }
   }
 }
