@@ -38,7 +38,7 @@ class Isect(C.Structure):
 
 
 class Raster(C.Structure):
-    _fields_ = [(n, F) for n in ("background", "render_colors", "render_alphas", "last_ids")]
+    _fields_ = [(n, F) for n in ("background", "render_colors", "render_alphas", "last_ids", "final_T")]
 
 
 class RasterGrads(C.Structure):

@@ -30,6 +30,7 @@ struct RasterBwdArgs {
   const float *out;     // forward render_colors (needed to undo the ED division)
   const float *alphas;
   const int32_t *last_ids;
+  const float *final_T;
   const float *v_out;
   const float *v_alphas;  // may be null
   float *isect_grad;
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
       const size_t pix = ((size_t)s * a.height + y) * a.width + x;
       last[p] = a.last_ids[pix];
       const float al = a.alphas[pix];
-      Tfin[p] = 1.f - al;
+      Tfin[p] = a.final_T[pix];
       const float *vp = a.v_out + pix * NCH;
 #pragma unroll
       for (int c = 0; c < NCH; c++) vo[p][c] = vp[c];
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
     const size_t pix = ((size_t)s * a.height + y) * a.width + x;
     last = a.last_ids[pix];
     const float al = a.alphas[pix];
-    const float Tfin = 1.f - al;
+    const float Tfin = a.final_T[pix];
     const float *vp = a.v_out + pix * NCH;
 #pragma unroll
     for (int c = 0; c < NCH; c++) vo[c] = vp[c];
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
     const size_t pix = ((size_t)s * a.height + y) * a.width + x;
     last = a.last_ids[pix];
     const float al = a.alphas[pix];
-    const float Tfin = 1.f - al;
+    const float Tfin = a.final_T[pix];
     const float *vp = a.v_out + pix * NCH;
 #pragma unroll
     for (int c = 0; c < NCH; c++) vo[c] = vp[c];
@@ -738,7 +739,7 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.ed = dims->depth_mode == D4GS_DEPTH_ED;
   a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
   a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.sorted_emit = isect->sorted_emit, a.tile_order = isect->tile_order;
-  a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids;
+  a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad;
   GatherArgs ga;
   ga.N = dims->N, ga.S = dims->S, ga.D = dims->D, ga.DP = (dims->D + 3) & ~3;

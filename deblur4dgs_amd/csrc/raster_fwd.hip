@@ -29,6 +29,7 @@ struct RasterFwdArgs {
   float *out;      // [S,H,W,NCH]
   float *alphas;   // [S,H,W]
   int32_t *last_ids;
+  float *final_T;
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n_blocks) {
@@ -126,6 +127,7 @@ __global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
       const size_t pix = ((size_t)s * a.height + y) * a.width + x;
       const float al = 1.f - T[p];
       a.alphas[pix] = al;
+      a.final_T[pix] = T[p];
       a.last_ids[pix] = last[p];
       float *o = a.out + pix * NCH;
 #pragma unroll
@@ -256,6 +258,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
     const size_t pix = ((size_t)s * a.height + y) * a.width + x;
     const float al = 1.f - T;
     a.alphas[pix] = al;
+    a.final_T[pix] = T;
     a.last_ids[pix] = last;
     float *o = a.out + pix * NCH;
 #pragma unroll
@@ -287,7 +290,7 @@ int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.ed = dims->depth_mode == D4GS_DEPTH_ED;
   a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
   a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.tile_order = isect->tile_order;
-  a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids;
+  a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
 #define D4GS_CASE(DD)                                                   \
   case DD:                                                              \

@@ -186,7 +186,8 @@ class RasterFn(torch.autograd.Function):
             to = st.proj_out["tile_offsets"]
             st.isect["tile_order"] = torch.argsort(to[1:] - to[:-1], descending=True).to(torch.int32)
         st.raster = dict(background=_f32c(background), render_colors=torch.empty(S, H, W, cfg.NCH, **f32),
-                         render_alphas=torch.empty(S, H, W, **f32), last_ids=torch.empty(S, H, W, **i32))
+                         render_alphas=torch.empty(S, H, W, **f32), last_ids=torch.empty(S, H, W, **i32),
+                         final_T=torch.empty(S, H, W, **f32))
         dims = cfg.dims()
         _, pout = _proj_structs(st)
         isect = L.fill(L.Isect(), **st.isect)
