@@ -75,6 +75,7 @@ __global__ void __launch_bounds__(256) k_emit(const EmitArgs a) {
 }
 
 // all-ascending bitonic network on `n` keys (any n): step (k, j) compares i with its partner l > i.
+// Generic form (used on global memory for lists beyond the LDS budget).
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr key, int n) {
   int P = 1;
@@ -98,6 +99,43 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, int n) {
   }
 }
 
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+  const int lo = __shfl_xor((int)(uint32_t)v, m), hi = __shfl_xor((int)(v >> 32), m);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// LDS form.  `key[0..P)` holds the list padded with UINT64_MAX to a power of two P >= 64.  All steps whose partner
+// distance is < 64 run inside one wave on a 64-key chunk held in registers (xor-shuffles, no LDS traffic, no
+// workgroup barrier); only the steps with distance >= 64 go through LDS with a barrier each.
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *key, int P) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int k = 2; k <= P; k <<= 1) {
+    int j = k >> 1;
+    for (; j >= 64; j >>= 1) {  // cross-chunk steps
+      for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+        const int blk = t / j, off = t - blk * j;
+        const int i = blk * 2 * j + off;
+        const int l = (j == (k >> 1)) ? (blk * 2 * j + (2 * j - 1 - off)) : (i + j);
+        const uint64_t a = key[i], b = key[l];
+        if (a > b) key[i] = b, key[l] = a;
+      }
+      __syncthreads();
+    }
+    // in-chunk steps j = min(k/2, 32) .. 1 on registers
+    for (int c = wv; c < (P >> 6); c += nw) {
+      uint64_t v = key[c * 64 + lane];
+      for (int jj = j; jj > 0; jj >>= 1) {
+        const int m = (jj == (k >> 1)) ? (k - 1) : jj;  // flip step of this k-block, else plain distance
+        const uint64_t o = shfl_xor_u64(v, m);
+        const bool lower = (lane & jj) == 0;  // for the flip mask k-1 the top set bit is jj as well
+        v = (lower == (v < o)) ? v : o;       // lower index keeps the min, upper the max
+      }
+      key[c * 64 + lane] = v;
+    }
+    __syncthreads();
+  }
+}
+
 struct SortArgs {
   const int32_t *tile_offsets;
   uint64_t *keys;
@@ -115,9 +153,11 @@ __global__ void __launch_bounds__(256) k_tile_sort(const SortArgs a) {
   if (n <= a.lo || (a.cap >= 0 && n > a.cap)) return;
   uint64_t *gk = a.keys + base;
   if (a.cap >= 0) {
-    for (int p = threadIdx.x; p < n; p += blockDim.x) skeys[p] = gk[p];
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) skeys[p] = p < n ? gk[p] : ~0ull;
     __syncthreads();
-    bitonic_sort(skeys, n);
+    bitonic_sort_lds(skeys, P);
     for (int p = threadIdx.x; p < n; p += blockDim.x) {
       const uint32_t e = (uint32_t)skeys[p];
       a.sorted_emit[base + p] = (int32_t)e;
