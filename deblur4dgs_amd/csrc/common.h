@@ -14,13 +14,6 @@
 void d4gs_set_error(const char *fmt, ...);
 int d4gs_check_launch(const char *what);
 
-struct float9 {
-  float m[9];
-};
-
-// clamp to [0,1]; lowers to the free `clamp` output modifier of the producing VALU op
-__device__ __forceinline__ float sat01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // 3x3 row-major helpers -----------------------------------------------------------------------
 __device__ __forceinline__ void mat3_mul(const float *A, const float *B, float *C) {  // C = A B
@@ -204,25 +197,6 @@ __device__ __forceinline__ void project_instance(const Cam &cam, const float *mw
   o.radius = (int)radius;
 }
 
-// wave64 sum: 6 DPP adds, total lands in lane 63 (GFX9 row_bcast forms).
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_add(float x) {
-  int v = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, true);
-  return x + __int_as_float(v);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float x) {
-  x = dpp_add<0xB1>(x);        // quad_perm [1,0,3,2]
-  x = dpp_add<0x4E>(x);        // quad_perm [2,3,0,1]
-  x = dpp_add<0x141>(x);       // row_half_mirror
-  x = dpp_add<0x140>(x);       // row_mirror  -> every lane holds its 16-lane row sum
-  x = dpp_add<0x142, 0xA>(x);  // row_bcast:15 into rows 1,3
-  x = dpp_add<0x143, 0xC>(x);  // row_bcast:31 into rows 2,3
-  return x;
-}
-__device__ __forceinline__ float wave_sum(float x) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(x)), 63));
-}
-
 // Optional per-kernel HIP-event profiler (off by default; used by bench.py for the roofline object).
 struct ProfScope {
   int slot;
@@ -230,6 +204,7 @@ struct ProfScope {
   ProfScope(const char *name, hipStream_t s);
   ~ProfScope();
 };
+
 // sigma * log2(e) of a splat at a pixel offset (dx, dy); g1 = conic pre-scaled by log2(e).  Used verbatim by both
 // forward variants AND the backward's alpha recomputation: explicit FMAs with contraction off, so every kernel (and
 // every unrolled copy of a loop body) rounds identically - the forward/backward valid-pixel decisions and the
@@ -241,11 +216,11 @@ __device__ __forceinline__ float splat_sigma2(const float4 g1, float dx, float d
   return __builtin_fmaf(0.5f, q, (g1.y * dx) * dy);
 }
 
-// ---- fused DPP wave reduction -------------------------------------------------------------------------------
-// hipcc lowers `x + update_dpp(x)` to v_mov_b32_dpp + v_add_f32 (2 issue slots per step).  These blocks issue the
-// fused v_add_f32_dpp instead: 6 instructions per value, total in lane 63.  Inside one asm block consecutive steps
-// on the same register are >= 3 instructions apart (DPP read-after-VALU-write needs 2 wait states); the short
-// blocks pad with s_nop.  The leading s_nop covers a compiler VALU write right before the block.
+// ---- fused DPP adds ------------------------------------------------------------------------------------------
+// hipcc lowers `x + update_dpp(x)` to v_mov_b32_dpp + v_add_f32 (2 issue slots per step).  The asm blocks below
+// issue the fused v_add_f32_dpp instead.  Inside one block consecutive steps on the same register are >= 3
+// instructions apart (DPP read-after-VALU-write needs 2 wait states); the short blocks pad with s_nop.  The
+// leading s_nop covers a compiler VALU write right before the block.
 #define D4GS_C1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0"
 #define D4GS_C2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0"
 #define D4GS_C3 "row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0"
@@ -253,41 +228,8 @@ __device__ __forceinline__ float splat_sigma2(const float4 g1, float dx, float d
 #define D4GS_C5 "row_bcast:15 row_mask:0xa bank_mask:0xf"
 #define D4GS_C6 "row_bcast:31 row_mask:0xc bank_mask:0xf"
 #define D4GS_DA(i, c) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " c "\n\t"
-#define D4GS_S4(c) D4GS_DA(0, c) D4GS_DA(1, c) D4GS_DA(2, c) D4GS_DA(3, c)
-#define D4GS_S8(c) D4GS_S4(c) D4GS_DA(4, c) D4GS_DA(5, c) D4GS_DA(6, c) D4GS_DA(7, c)
 #define D4GS_S2(c) D4GS_DA(0, c) D4GS_DA(1, c) "s_nop 0\n\t"
 #define D4GS_S1(c) D4GS_DA(0, c) "s_nop 1\n\t"
-__device__ __forceinline__ void wsum8(float &a, float &b, float &c, float &d, float &e, float &f, float &g, float &h) {
-  asm volatile("s_nop 1\n\t" D4GS_S8(D4GS_C1) D4GS_S8(D4GS_C2) D4GS_S8(D4GS_C3) D4GS_S8(D4GS_C4) D4GS_S8(D4GS_C5)
-                   D4GS_S8(D4GS_C6)
-               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
-}
-__device__ __forceinline__ void wsum4(float &a, float &b, float &c, float &d) {
-  asm volatile("s_nop 1\n\t" D4GS_S4(D4GS_C1) D4GS_S4(D4GS_C2) D4GS_S4(D4GS_C3) D4GS_S4(D4GS_C4) D4GS_S4(D4GS_C5)
-                   D4GS_S4(D4GS_C6)
-               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-}
-__device__ __forceinline__ void wsum2(float &a, float &b) {
-  asm volatile("s_nop 1\n\t" D4GS_S2(D4GS_C1) D4GS_S2(D4GS_C2) D4GS_S2(D4GS_C3) D4GS_S2(D4GS_C4) D4GS_S2(D4GS_C5)
-                   D4GS_S2(D4GS_C6)
-               : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void wsum1(float &a) {
-  asm volatile("s_nop 1\n\t" D4GS_S1(D4GS_C1) D4GS_S1(D4GS_C2) D4GS_S1(D4GS_C3) D4GS_S1(D4GS_C4) D4GS_S1(D4GS_C5)
-                   D4GS_S1(D4GS_C6)
-               : "+v"(a));
-}
-// sum each of v[0..R) over the wave; totals valid in lane 63
-template <int R>
-__device__ __forceinline__ void wave_sum_array_lane63(float (&v)[R]) {
-  constexpr int n8 = R / 8, r8 = R % 8, n4 = r8 / 4, r4 = r8 % 4, n2 = r4 / 2, n1 = r4 % 2;
-#pragma unroll
-  for (int i = 0; i < n8; i++)
-    wsum8(v[8 * i], v[8 * i + 1], v[8 * i + 2], v[8 * i + 3], v[8 * i + 4], v[8 * i + 5], v[8 * i + 6], v[8 * i + 7]);
-  if constexpr (n4) wsum4(v[8 * n8], v[8 * n8 + 1], v[8 * n8 + 2], v[8 * n8 + 3]);
-  if constexpr (n2) wsum2(v[8 * n8 + 4 * n4], v[8 * n8 + 4 * n4 + 1]);
-  if constexpr (n1) wsum1(v[R - 1]);
-}
 
 // ---- wave reduction with gfx950 permlane swaps ---------------------------------------------------------------
 // v_permlane32_swap / v_permlane16_swap fold TWO registers per instruction, so R per-lane values are reduced in

@@ -25,7 +25,6 @@ struct RasterBwdArgs {
   const float *background;
   const int32_t *tile_offsets;
   const int32_t *sorted_gid;
-  const int32_t *tile_order;
   const int32_t *sorted_emit;
   const float *out;     // forward render_colors (needed to undo the ED division)
   const float *alphas;
@@ -61,8 +60,7 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
 
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
-  const int t = a.tile_order ? (blockIdx.x < n_tiles ? a.tile_order[blockIdx.x] : n_tiles)
-                             : xcd_remap_b(blockIdx.x, n_tiles);
+  const int t = xcd_remap_b(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   if (end <= start) return;
@@ -235,7 +233,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
 
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
-  const int t = a.tile_order ? (blockIdx.x < n_tiles ? a.tile_order[blockIdx.x] : n_tiles) : xcd_remap_b(blockIdx.x, n_tiles);
+  const int t = xcd_remap_b(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   if (end <= start) return;
@@ -433,7 +431,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
 
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
-  const int t = a.tile_order ? (blockIdx.x < n_tiles ? a.tile_order[blockIdx.x] : n_tiles) : xcd_remap_b(blockIdx.x, n_tiles);
+  const int t = xcd_remap_b(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   if (end <= start) return;
@@ -738,7 +736,7 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   a.ed = dims->depth_mode == D4GS_DEPTH_ED;
   a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
-  a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.sorted_emit = isect->sorted_emit, a.tile_order = isect->tile_order;
+  a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.sorted_emit = isect->sorted_emit;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad;
   GatherArgs ga;

@@ -25,7 +25,6 @@ struct RasterFwdArgs {
   const float *background;  // [D] or null
   const int32_t *tile_offsets;
   const int32_t *sorted_gid;
-  const int32_t *tile_order;
   float *out;      // [S,H,W,NCH]
   float *alphas;   // [S,H,W]
   int32_t *last_ids;
@@ -49,8 +48,7 @@ __global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
 
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
-  const int t = a.tile_order ? (blockIdx.x < n_tiles ? a.tile_order[blockIdx.x] : n_tiles)
-                             : xcd_remap(blockIdx.x, n_tiles);
+  const int t = xcd_remap(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
   const int ty = tl / a.tw, tx = tl - ty * a.tw;
@@ -161,7 +159,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
 
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
-  const int t = a.tile_order ? (blockIdx.x < n_tiles ? a.tile_order[blockIdx.x] : n_tiles) : xcd_remap(blockIdx.x, n_tiles);
+  const int t = xcd_remap(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
   const int ty = tl / a.tw, tx = tl - ty * a.tw;
@@ -289,7 +287,7 @@ int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   a.ed = dims->depth_mode == D4GS_DEPTH_ED;
   a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
-  a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.tile_order = isect->tile_order;
+  a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
 #define D4GS_CASE(DD)                                                   \

@@ -69,9 +69,6 @@ class State:
     n_isect: int = -1
 
 
-TILE_ORDER = False  # experiment: heaviest-tile-first launch order
-
-
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -181,10 +178,7 @@ class RasterFn(torch.autograd.Function):
         st.n_isect = n
         m = max(n, 1)
         st.isect = dict(keys=torch.empty(m, dtype=torch.int64, device=dev), gid_of_emit=torch.empty(m, **i32),
-                        sorted_gid=torch.empty(m, **i32), sorted_emit=torch.empty(m, **i32), tile_order=None)
-        if TILE_ORDER:
-            to = st.proj_out["tile_offsets"]
-            st.isect["tile_order"] = torch.argsort(to[1:] - to[:-1], descending=True).to(torch.int32)
+                        sorted_gid=torch.empty(m, **i32), sorted_emit=torch.empty(m, **i32))
         st.raster = dict(background=_f32c(background), render_colors=torch.empty(S, H, W, cfg.NCH, **f32),
                          render_alphas=torch.empty(S, H, W, **f32), last_ids=torch.empty(S, H, W, **i32),
                          final_T=torch.empty(S, H, W, **f32))

@@ -107,8 +107,6 @@ typedef struct D4gsIsect {
   int32_t *gid_of_emit;    /* [n_isect] Gaussian id of each emission index */
   int32_t *sorted_gid;     /* [n_isect] per-tile depth-sorted Gaussian ids (flatten_ids) */
   int32_t *sorted_emit;    /* [n_isect] emission index of each sorted slot */
-  const int32_t *tile_order; /* [S*tiles] or NULL: launch order of the (sub-sample, tile) work items, heaviest
-                                first (longest-processing-time-first balancing of the one-wave-per-tile kernels) */
 } D4gsIsect;
 
 typedef struct D4gsRaster {
