@@ -34,7 +34,7 @@ class ProjOut(C.Structure):
 
 
 class Isect(C.Structure):
-    _fields_ = [("n_isect", C.c_int64)] + [(n, F) for n in ("keys", "gid_of_emit", "sorted_gid", "sorted_emit")]
+    _fields_ = [("n_isect", C.c_int64), ("max_tile_count", C.c_int64)] + [(n, F) for n in ("keys", "gid_of_emit", "sorted_gid", "sorted_emit")]
 
 
 class Raster(C.Structure):

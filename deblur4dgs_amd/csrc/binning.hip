@@ -208,7 +208,8 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   }
   const int classes[3][2] = {{0, 2048}, {2048, 16384}, {16384, -1}};
   for (int c = 0; c < 3; c++) {
-    if (c > 0 && isect->n_isect <= classes[c][0]) break;  // no list can be that long
+    const int64_t longest = isect->max_tile_count > 0 ? isect->max_tile_count : isect->n_isect;
+    if (c > 0 && longest <= classes[c][0]) break;  // no list is that long
     SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
                classes[c][0], classes[c][1]};
     const size_t lds = classes[c][1] > 0 ? (size_t)classes[c][1] * 8 : 0;

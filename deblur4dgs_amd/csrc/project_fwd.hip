@@ -238,20 +238,30 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(const int *in, int64
 // single block: exclusive scan of `n` ints in place (looping with a carry); optionally writes the total to
 // out[n] (int32) and to total64.
 __global__ void __launch_bounds__(1024) k_scan_single(const int *in, const int *in2, int *out, int64_t n, int write_last,
-                                                       int64_t *total64) {
+                                                       int64_t *total64, int64_t *max64) {
   __shared__ int lds[20];
+  __shared__ int smax;
+  if (threadIdx.x == 0) smax = 0;
+  __syncthreads();
   int64_t carry = 0;
+  int vmax = 0;
   for (int64_t base = 0; base < n; base += blockDim.x) {
     int64_t i = base + threadIdx.x;
     int v = i < n ? in[i] + (in2 ? in2[i] : 0) : 0;
+    vmax = max(vmax, v);
     int tot;
     int ex = block_exclusive_scan(v, &tot, lds);
     if (i < n) out[i] = (int)(carry + ex);
     carry += tot;
   }
+  if (max64) {
+    atomicMax(&smax, vmax);
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     if (write_last) out[n] = (int)carry;
     if (total64) *total64 = carry;
+    if (max64) *max64 = smax;
   }
 }
 
@@ -331,10 +341,10 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   D4GS_LAUNCH("k_scan_sums", k_scan_sums, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, n_inst,
                      out->scan_ws);
   D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->scan_ws, (const int *)nullptr, out->scan_ws, (int64_t)sblocks, 0,
-                     out->n_isect);
+                     out->n_isect, (int64_t *)nullptr);
   D4GS_LAUNCH("k_scan_apply", k_scan_apply, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, out->scan_ws,
                      n_inst, out->isect_offsets);
   D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->tile_counts, (const int *)(out->tile_counts + n_tiles), out->tile_offsets, n_tiles, 1,
-                     (int64_t *)nullptr);
+                     (int64_t *)nullptr, out->n_isect + 1);
   return d4gs_check_launch("scan");
 }

@@ -67,6 +67,7 @@ class State:
     isect: dict = field(default_factory=dict)
     raster: dict = field(default_factory=dict)
     n_isect: int = -1
+    max_tile: int = -1
 
 
 def _stream():
@@ -111,7 +112,7 @@ class ProjectFn(torch.autograd.Function):
             tiles_touched=torch.empty(S * N, **i32),
             isect_offsets=torch.empty(S * N, **i32), tile_ranks=torch.empty(S * N, 8, **i32),
             tile_counts=torch.empty(2 * S * tw * th, **i32),
-            tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(1, dtype=torch.int64, device=dev),
+            tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(2, dtype=torch.int64, device=dev),
             scan_ws=torch.empty(lib.d4gs_scan_ws_elems(S * N), **i32),
         )
         dims = cfg.dims()
@@ -174,8 +175,8 @@ class RasterFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         lib = L.lib()
-        n = int(st.proj_out["n_isect"].item())  # the one host sync of the forward pass (sizes the lists)
-        st.n_isect = n
+        n, max_tile = st.proj_out["n_isect"].tolist()  # the one host sync of the forward pass (sizes the lists)
+        st.n_isect, st.max_tile = n, max_tile
         m = max(n, 1)
         st.isect = dict(keys=torch.empty(m, dtype=torch.int64, device=dev), gid_of_emit=torch.empty(m, **i32),
                         sorted_gid=torch.empty(m, **i32), sorted_emit=torch.empty(m, **i32))
@@ -185,7 +186,7 @@ class RasterFn(torch.autograd.Function):
         dims = cfg.dims()
         _, pout = _proj_structs(st)
         isect = L.fill(L.Isect(), **st.isect)
-        isect.n_isect = n
+        isect.n_isect, isect.max_tile_count = n, max_tile
         ras = L.fill(L.Raster(), **st.raster)
         L.check(lib.d4gs_bin_sort(C.byref(dims), C.byref(pout), C.byref(isect), _stream()), "d4gs_bin_sort")
         L.check(lib.d4gs_raster_fwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), _stream()),
@@ -214,7 +215,7 @@ class RasterFn(torch.autograd.Function):
         dims = cfg.dims()
         _, pout = _proj_structs(st)
         isect = L.fill(L.Isect(), **st.isect)
-        isect.n_isect = st.n_isect
+        isect.n_isect, isect.max_tile_count = st.n_isect, st.max_tile
         ras = L.fill(L.Raster(), **st.raster)
         rg = L.fill(L.RasterGrads(), **g)
         L.check(lib.d4gs_raster_bwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), C.byref(rg), _stream()),

@@ -97,12 +97,14 @@ typedef struct D4gsProjOut {
   int32_t *tile_counts;    /* [2*S*tiles]: [0,T) splats per tile that carry ranks, [T,2T) wide splats per tile
                               (consumed as cursors by d4gs_bin_sort); T = S*tiles */
   int32_t *tile_offsets;   /* [S*tiles+1] exclusive scan of tile_counts */
-  int64_t *n_isect;        /* [1] total intersections (read back by the host to size the next stage) */
+  int64_t *n_isect;        /* [2] {total intersections, longest tile list} - read back by the host to size the next
+                              stage and to pick the sort size classes */
   int32_t *scan_ws;        /* [d4gs_scan_ws_elems(S*N)] scratch */
 } D4gsProjOut;
 
 typedef struct D4gsIsect {
-  int64_t n_isect;         /* [host] value read back from D4gsProjOut.n_isect */
+  int64_t n_isect;         /* [host] D4gsProjOut.n_isect[0] */
+  int64_t max_tile_count;  /* [host] D4gsProjOut.n_isect[1] (<= 0: unknown, launch every sort class) */
   uint64_t *keys;          /* [n_isect] scratch: (depth bits << 32 | emission index) per tile slot */
   int32_t *gid_of_emit;    /* [n_isect] Gaussian id of each emission index */
   int32_t *sorted_gid;     /* [n_isect] per-tile depth-sorted Gaussian ids (flatten_ids) */
