@@ -256,3 +256,24 @@ def test_single_gaussian_and_api_errors():
     with pytest.raises(RuntimeError):  # CPU tensors: no fallback
         rasterization(torch.zeros(1, 3), torch.zeros(1, 4), torch.ones(1, 3), torch.ones(1), torch.ones(1, 3),
                       torch.eye(4)[None], K.cpu(), 40, 24)
+
+
+@pytest.mark.parametrize("mode,D", [("RGB+D", 3), ("RGB", 1), ("RGB+ED", 2), ("RGB+ED", 6), ("RGB", 7), ("RGB+ED", 8)])
+def test_channel_counts_padding_and_depth_modes(mode, D):
+    """Every channel instantiation (1,2,3,4,5,8,16) incl. host-side padding of odd counts (6,7 -> 8), the un-normalised
+    depth mode RGB+D, and no background - forward and colour / opacity / means gradients."""
+    W, H, N = 80, 56, 900
+    inp = static_inputs(N, W, H, seed=400 + D, dtype=torch.float64, D=D)
+    t = {k: v.clone().requires_grad_(k != "K") for k, v in inp.items()}
+    ref_c, ref_a, _ = raster.rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"], t["K"],
+                                           W, H, background=None, render_mode=mode)
+    g = torch.Generator().manual_seed(D)
+    wc = torch.randn(ref_c.shape, generator=g, dtype=torch.float64)
+    ((ref_c * wc).sum() + ref_a.sum()).backward()
+    rc, ra, info, tg = _run_gpu(inp, W, H, mode, None, requires_grad=True)
+    assert rc.shape == (1, H, W, D + (mode != "RGB"))
+    ((rc[0] * wc.float().to(rc.device)).sum() + ra.sum()).backward()
+    torch.cuda.synchronize()
+    assert frac_bad(rc[0].cpu(), ref_c, 1e-4) < 2e-3, rel_err(rc[0].cpu(), ref_c)
+    for name in ("means", "opac", "colors"):
+        assert frac_bad(tg[name].grad.cpu(), t[name].grad, 1e-3) < 3e-3, (name, rel_err(tg[name].grad.cpu(), t[name].grad))
