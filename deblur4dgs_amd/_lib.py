@@ -59,7 +59,8 @@ GEOM_STRIDE = 8
 EXPORTS = (
     "d4gs_version", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
-    "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_control_stats", "d4gs_profile_enable", "d4gs_profile_collect",
+    "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_control_stats", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
+    "d4gs_pose_encode", "d4gs_profile_enable", "d4gs_profile_collect",
 )
 
 _lib = None
@@ -92,6 +93,9 @@ def lib() -> C.CDLL:
         L.d4gs_points_fwd.argtypes = [P(Dims), P(ProjIn), vp, vp]
         L.d4gs_points_bwd.argtypes = [P(Dims), P(ProjIn), vp, P(LeafGrads), vp]
         L.d4gs_control_stats.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, vp]
+        L.d4gs_camera_path_fwd.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_float, vp, vp, vp, vp, vp, vp]
+        L.d4gs_camera_path_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
+        L.d4gs_pose_encode.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp]
         L.d4gs_blend_fwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp]
         L.d4gs_blend_bwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp, vp, vp]
         if L.d4gs_version() != 100:

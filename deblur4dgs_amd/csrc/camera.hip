@@ -1,0 +1,311 @@
+// camera.hip -- a12: the camera-delta / exposure-time generator that feeds the rasterizer `RTs [S,3,4]`, `times [S]`.
+//
+// Reference: MoveModel.forward_start_end_mid (flow3d/models/move_model.py:138-166) ->
+//   pypose se3.Exp of the two MLP head outputs, linear_interpolation (spline_utils.py:371-408: lerp t, slerp q),
+//   SE3.Log, se3_to_SE3 (spline_utils.py:197-215, reading the [tau,phi] log as [w,u] -- move_model.py:146-147),
+//   and the exposure-time lerp with the relu/clamp'ed per-frame half-width (move_model.py:118-135,151-158);
+//   MoveModel.preprocessPose + positional embedding (move_model.py:12-63,104-110; spline_utils.py:177-195).
+//
+// In eager PyTorch that chain is ~700 tiny kernels forward and ~1500 backward per render (three renders per
+// training step); it is latency, not work: 12 differentiable inputs, 12*S outputs.  Here it is ONE launch: thread
+// (s, j) evaluates sub-sample s in dual-number arithmetic carrying the tangent d/d delta[j], so the forward writes
+// the poses AND the full Jacobian [S,12,12]; the backward is a 12S x 12 mat-vec in a second tiny kernel.
+#include "common.h"
+
+namespace {
+
+// ---- first-order dual numbers -----------------------------------------------------------------------------
+struct Dual {
+  float v, d;
+};
+__device__ inline Dual mk(float v, float d = 0.f) { return Dual{v, d}; }
+__device__ inline Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ inline Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ inline Dual operator-(Dual a) { return {-a.v, -a.d}; }
+__device__ inline Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ inline Dual operator/(Dual a, Dual b) {
+  float q = a.v / b.v;
+  return {q, (a.d - q * b.d) / b.v};
+}
+__device__ inline Dual operator+(Dual a, float b) { return {a.v + b, a.d}; }
+__device__ inline Dual operator+(float a, Dual b) { return {a + b.v, b.d}; }
+__device__ inline Dual operator-(Dual a, float b) { return {a.v - b, a.d}; }
+__device__ inline Dual operator-(float a, Dual b) { return {a - b.v, -b.d}; }
+__device__ inline Dual operator*(Dual a, float b) { return {a.v * b, a.d * b}; }
+__device__ inline Dual operator*(float a, Dual b) { return {a * b.v, a * b.d}; }
+__device__ inline Dual operator/(Dual a, float b) { return {a.v / b, a.d / b}; }
+__device__ inline Dual operator/(float a, Dual b) { return mk(a) / b; }
+__device__ inline Dual Sqrt(Dual a) {
+  float s = sqrtf(a.v);
+  return {s, a.d / (2.f * s)};
+}
+__device__ inline Dual Sin(Dual a) { return {sinf(a.v), cosf(a.v) * a.d}; }
+__device__ inline Dual Cos(Dual a) { return {cosf(a.v), -sinf(a.v) * a.d}; }
+__device__ inline Dual Atan(Dual a) { return {atanf(a.v), a.d / (1.f + a.v * a.v)}; }
+
+// plain floats through the same templates (pose encoding carries no tangent)
+__device__ inline float mkT(float v, float *) { return v; }
+__device__ inline Dual mkT(float v, Dual *) { return mk(v); }
+__device__ inline float Sqrt(float a) { return sqrtf(a); }
+__device__ inline float val(float a) { return a; }
+__device__ inline float val(Dual a) { return a.v; }
+__device__ inline float zero_tangent(float a) { return a; }
+__device__ inline Dual zero_tangent(Dual a) { return mk(a.v); }
+
+template <typename T>
+struct V3 {
+  T x, y, z;
+};
+template <typename T>
+struct M3 {
+  T m[3][3];
+};
+
+template <typename T>
+__device__ inline T dot(V3<T> a, V3<T> b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+template <typename T>
+__device__ inline V3<T> cross(V3<T> a, V3<T> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename T>
+__device__ inline M3<T> skew(V3<T> w) {
+  T O = mkT(0.f, (T *)nullptr);
+  M3<T> K;
+  K.m[0][0] = O, K.m[0][1] = -w.z, K.m[0][2] = w.y;
+  K.m[1][0] = w.z, K.m[1][1] = O, K.m[1][2] = -w.x;
+  K.m[2][0] = -w.y, K.m[2][1] = w.x, K.m[2][2] = O;
+  return K;
+}
+template <typename T>
+__device__ inline M3<T> matmul(const M3<T> &a, const M3<T> &b) {
+  M3<T> c;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+  return c;
+}
+template <typename T>
+__device__ inline V3<T> matvec(const M3<T> &a, V3<T> v) {
+  return {a.m[0][0] * v.x + a.m[0][1] * v.y + a.m[0][2] * v.z, a.m[1][0] * v.x + a.m[1][1] * v.y + a.m[1][2] * v.z,
+          a.m[2][0] * v.x + a.m[2][1] * v.y + a.m[2][2] * v.z};
+}
+// I*ci + a*K + b*K2
+template <typename T>
+__device__ inline M3<T> eye_plus(float ci, T a, const M3<T> &K, T b, const M3<T> &K2) {
+  M3<T> r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.m[i][j] = (i == j ? ci : 0.f) + a * K.m[i][j] + b * K2.m[i][j];
+  return r;
+}
+
+// L2 norm with torch's sub-gradient 0 at the origin (the zero-initialised heads sit exactly there)
+template <typename T>
+__device__ inline T norm3(V3<T> w) {
+  T n2 = w.x * w.x + w.y * w.y + w.z * w.z;
+  if (val(n2) == 0.f) return mkT(0.f, (T *)nullptr);
+  return Sqrt(n2);
+}
+
+// spline_utils.py:20-54: sum_{i<=10} (-1)^i x^(2i) / denom_i, the reference's term order
+template <typename T>
+__device__ inline T taylor(T x, int kind) {
+  T x2 = x * x, p = mkT(1.f, (T *)nullptr), ans = mkT(0.f, (T *)nullptr);
+  double denom = 1.0;
+  for (int i = 0; i <= 10; ++i) {
+    double step = kind == 0 ? (i > 0 ? (2.0 * i) * (2.0 * i + 1) : 1.0)
+                            : (kind == 1 ? (2.0 * i + 1) * (2.0 * i + 2) : (2.0 * i + 2) * (2.0 * i + 3));
+    denom *= step;
+    if (i > 0) p = p * x2;
+    ans = ans + ((i & 1) ? -1.f : 1.f) * p / (float)denom;
+  }
+  return ans;
+}
+
+// pypose-style guarded coefficient: theta^2 > eps ? big(theta) : small(theta^2)
+#define D4GS_GUARDED(t2, th, BIG, SMALL) ((t2).v > 1e-12f ? ([&](Dual th) { return BIG; })(Sqrt(t2)) : ([&](Dual x) { return SMALL; })(t2))
+
+struct Q4 {
+  V3<Dual> v;
+  Dual w;
+};
+
+__device__ inline Q4 so3_exp(V3<Dual> phi) {
+  Dual t2 = dot(phi, phi);
+  Dual im = D4GS_GUARDED(t2, th, Sin(0.5f * th) / th, 0.5f - x / 48.f + x * x / 3840.f);
+  Dual re = D4GS_GUARDED(t2, th, Cos(0.5f * th), 1.f - x / 8.f + x * x / 384.f);
+  return {{phi.x * im, phi.y * im, phi.z * im}, re};
+}
+__device__ inline V3<Dual> so3_log(Q4 q) {
+  Dual n2 = dot(q.v, q.v);
+  Dual w = q.w;
+  Dual f = D4GS_GUARDED(n2, n, 2.f * Atan(n / w) / n, 2.f / w - 2.f * x / (3.f * w * w * w));
+  return {f * q.v.x, f * q.v.y, f * q.v.z};
+}
+__device__ inline Q4 so3_mul(Q4 p, Q4 q) {
+  V3<Dual> c = cross(p.v, q.v);
+  return {{p.w * q.v.x + q.w * p.v.x + c.x, p.w * q.v.y + q.w * p.v.y + c.y, p.w * q.v.z + q.w * p.v.z + c.z},
+          p.w * q.w - dot(p.v, q.v)};
+}
+__device__ inline Q4 so3_inv(Q4 q) { return {{-q.v.x, -q.v.y, -q.v.z}, q.w}; }
+
+__device__ inline M3<Dual> left_jacobian(V3<Dual> phi) {
+  Dual t2 = dot(phi, phi);
+  M3<Dual> K = skew(phi), K2 = matmul(K, K);
+  Dual c1 = D4GS_GUARDED(t2, th, (1.f - Cos(th)) / (th * th), 0.5f - x / 24.f);
+  Dual c2 = D4GS_GUARDED(t2, th, (th - Sin(th)) / (th * th * th), 1.f / 6.f - x / 120.f);
+  return eye_plus(1.f, c1, K, c2, K2);
+}
+__device__ inline M3<Dual> left_jacobian_inv(V3<Dual> phi) {
+  Dual t2 = dot(phi, phi);
+  M3<Dual> K = skew(phi), K2 = matmul(K, K);
+  Dual c2 = D4GS_GUARDED(t2, th, (1.f - th * Cos(0.5f * th) / (2.f * Sin(0.5f * th))) / (th * th), 1.f / 12.f + x / 720.f);
+  return eye_plus(1.f, mk(-0.5f), K, c2, K2);
+}
+
+struct SE3 {
+  V3<Dual> t;
+  Q4 q;
+};
+__device__ inline SE3 se3_exp(const Dual *xi) {  // [tau, phi]
+  V3<Dual> tau = {xi[0], xi[1], xi[2]}, phi = {xi[3], xi[4], xi[5]};
+  return {matvec(left_jacobian(phi), tau), so3_exp(phi)};
+}
+
+// ---- forward: thread (s, j) -------------------------------------------------------------------------------
+__global__ void k_camera_path(const float *__restrict__ delta0, const float *__restrict__ delta1, int S,
+                              const float *__restrict__ time_params, int index, float t, int moving,
+                              float *__restrict__ RTs, float *__restrict__ jac, float *__restrict__ times,
+                              float *__restrict__ dtimes, float *__restrict__ deltaT) {
+  int tid = threadIdx.x + blockIdx.x * blockDim.x;
+  int s = tid / 12, j = tid % 12;
+  if (s >= S) return;
+  Dual a[6], b[6];
+  for (int k = 0; k < 6; ++k) a[k] = mk(delta0[k], j == k ? 1.f : 0.f), b[k] = mk(delta1[k], j == k + 6 ? 1.f : 0.f);
+  SE3 X0 = se3_exp(a), X1 = se3_exp(b);
+  // torch.linspace(0, 1, S): start + step*i below the midpoint, end - step*(S-1-i) above it
+  float stepu = S > 1 ? 1.f / (float)(S - 1) : 0.f;
+  float u = s < S / 2 ? stepu * (float)s : 1.f - stepu * (float)(S - 1 - s);
+  if (S == 1) u = 0.f;
+  V3<Dual> tt = {(1.f - u) * X0.t.x + u * X1.t.x, (1.f - u) * X0.t.y + u * X1.t.y, (1.f - u) * X0.t.z + u * X1.t.z};
+  V3<Dual> r = so3_log(so3_mul(so3_inv(X0.q), X1.q));
+  Q4 q = so3_mul(X0.q, so3_exp({u * r.x, u * r.y, u * r.z}));
+  // SE3.Log -> [tau, phi]; se3_to_SE3 reads it as [w, u]
+  V3<Dual> phi = so3_log(q);
+  V3<Dual> w = matvec(left_jacobian_inv(phi), tt);
+  M3<Dual> wx = skew(w), wx2 = matmul(wx, wx);
+  Dual theta = norm3(w);
+  Dual A = taylor(theta, 0), B = taylor(theta, 1), Cc = taylor(theta, 2);
+  M3<Dual> R = eye_plus(1.f, A, wx, B, wx2), V = eye_plus(1.f, B, wx, Cc, wx2);
+  V3<Dual> Vu = matvec(V, phi);
+  Dual out[12] = {R.m[0][0], R.m[0][1], R.m[0][2], Vu.x, R.m[1][0], R.m[1][1], R.m[1][2], Vu.y,
+                  R.m[2][0], R.m[2][1], R.m[2][2], Vu.z};
+  for (int i = 0; i < 12; ++i) {
+    if (jac) jac[((size_t)s * 12 + i) * 12 + j] = out[i].d;
+    if (j == 0) RTs[s * 12 + i] = out[i].v;
+  }
+  if (j == 0) {
+    // move_model.py:118-135,151-158: half-width d = clamp(relu(p), 0.1, 0.9) on interior frames of stage 2, else 0
+    float d = 0.f, gate = 0.f;
+    if (moving) {
+      float p = time_params[index];
+      float rl = p > 0.f ? p : 0.f;
+      d = fminf(fmaxf(rl, 0.1f), 0.9f);
+      gate = (p > 0.f && rl >= 0.1f && rl <= 0.9f) ? 1.f : 0.f;
+    }
+    float wgt = (float)s / (float)(S - 1);  // arange(S) / (S-1); NaN for S == 1 exactly as the reference
+    float t0 = d * -1.0f + t, t1 = d * 1.0f + t;
+    times[s] = t0 * (1.0f - wgt) + t1 * wgt;
+    dtimes[s] = gate * (wgt - (1.0f - wgt));
+    if (s == 0) deltaT[0] = fabsf(d * 1.0f), deltaT[1] = gate;  // [value, d value / d p]
+  }
+}
+
+// ---- backward: v_delta[j] = sum_{s,i} v_RTs[s,i] * jac[s,i,j];  v_time_params[index] ---------------------
+__global__ void k_camera_path_bwd(const float *__restrict__ jac, const float *__restrict__ dtimes,
+                                  const float *__restrict__ deltaT, const float *__restrict__ v_RTs,
+                                  const float *__restrict__ v_times, const float *__restrict__ v_deltaT, int S,
+                                  int index, int n_time_params, float *__restrict__ v_delta0,
+                                  float *__restrict__ v_delta1, float *__restrict__ v_time_params) {
+  int j = threadIdx.x;
+  if (j < 12) {
+    float acc = 0.f;
+    if (v_RTs)
+      for (int k = 0; k < S * 12; ++k) acc += v_RTs[k] * jac[(size_t)k * 12 + j];
+    (j < 6 ? v_delta0[j] : v_delta1[j - 6]) = acc;
+  } else if (j < 12 + n_time_params) {
+    int p = j - 12;
+    float acc = 0.f;
+    if (p == index) {
+      if (v_times)
+        for (int s = 0; s < S; ++s) acc += v_times[s] * dtimes[s];
+      if (v_deltaT) acc += v_deltaT[0] * deltaT[1];
+    }
+    v_time_params[p] = acc;
+  }
+}
+
+// ---- pose encoding (no tangent): SE3_to_se3 + positional embedding -----------------------------------------
+__global__ void k_pose_encode(const float *__restrict__ Rp, int r_stride, const float *__restrict__ Tp, int t_stride,
+                              float *__restrict__ enc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float R[9], T[3];
+  for (int i = 0; i < 3; ++i) {
+    T[i] = Tp[i * t_stride];
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rp[i * r_stride + j];
+  }
+  // SO3_to_so3 (spline_utils.py:177-184)
+  float trace = R[0] + R[4] + R[8];
+  float c = fminf(fmaxf((trace - 1.f) / 2.f, -1.f + 1e-7f), 1.f - 1e-7f);
+  float theta = acosf(c);
+  theta = fmodf(theta, 3.14159265358979323846f);  // `% math.pi`, acos >= 0
+  float A = taylor(theta, 0);
+  float f = 1.f / (2.f * A + 1e-8f);
+  V3<float> w = {f * (R[7] - R[5]), f * (R[2] - R[6]), f * (R[3] - R[1])};
+  // SE3_to_se3 (spline_utils.py:187-195)
+  M3<float> wx = skew(w), wx2 = matmul(wx, wx);
+  float th = Sqrt(w.x * w.x + w.y * w.y + w.z * w.z);
+  float A2 = taylor(th, 0), B2 = taylor(th, 1);
+  float cc = (1.f - A2 / (2.f * B2)) / (th * th + 1e-8f);
+  M3<float> invV = eye_plus(1.f, -0.5f, wx, cc, wx2);
+  V3<float> tv = {T[0], T[1], T[2]};
+  V3<float> u = matvec(invV, tv);
+  float x[6] = {w.x, w.y, w.z, u.x, u.y, u.z};
+  // move_model.py:12-63: [x, sin(x f), cos(x f)] for f = 1, 2, 4, 8, 16
+  for (int k = 0; k < 6; ++k) enc[k] = x[k];
+  float fr = 1.f;
+  for (int l = 0; l < 5; ++l, fr *= 2.f)
+    for (int k = 0; k < 6; ++k) {
+      enc[6 + 12 * l + k] = sinf(x[k] * fr);
+      enc[6 + 12 * l + 6 + k] = cosf(x[k] * fr);
+    }
+}
+
+}  // namespace
+
+int d4gs_pose_encode_impl(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc,
+                          hipStream_t stream) {
+  ProfScope ps("k_pose_encode", stream);
+  k_pose_encode<<<1, 64, 0, stream>>>(R, r_stride, T, t_stride, enc);
+  return d4gs_check_launch("k_pose_encode");
+}
+
+int d4gs_camera_path_fwd_impl(const float *delta0, const float *delta1, int32_t S, const float *time_params,
+                              int32_t index, float t, int32_t moving, float *RTs, float *jac, float *times,
+                              float *dtimes, float *deltaT, hipStream_t stream) {
+  ProfScope ps("k_camera_path", stream);
+  int threads = S * 12;
+  k_camera_path<<<(threads + 63) / 64, 64, 0, stream>>>(delta0, delta1, S, time_params, index, t, moving, RTs, jac,
+                                                         times, dtimes, deltaT);
+  return d4gs_check_launch("k_camera_path");
+}
+
+int d4gs_camera_path_bwd_impl(const float *jac, const float *dtimes, const float *deltaT, const float *v_RTs,
+                              const float *v_times, const float *v_deltaT, int32_t S, int32_t index,
+                              int32_t n_time_params, float *v_delta0, float *v_delta1, float *v_time_params,
+                              hipStream_t stream) {
+  ProfScope ps("k_camera_path_bwd", stream);
+  k_camera_path_bwd<<<1, 64, 0, stream>>>(jac, dtimes, deltaT, v_RTs, v_times, v_deltaT, S, index, n_time_params,
+                                          v_delta0, v_delta1, v_time_params);
+  return d4gs_check_launch("k_camera_path_bwd");
+}

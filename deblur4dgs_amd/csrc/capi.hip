@@ -20,6 +20,12 @@ int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float 
 int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
                         const float *, float *, float *, hipStream_t);
 
+int d4gs_pose_encode_impl(const float *, int32_t, const float *, int32_t, float *, hipStream_t);
+int d4gs_camera_path_fwd_impl(const float *, const float *, int32_t, const float *, int32_t, float, int32_t, float *,
+                              float *, float *, float *, float *, hipStream_t);
+int d4gs_camera_path_bwd_impl(const float *, const float *, const float *, const float *, const float *,
+                              const float *, int32_t, int32_t, int32_t, float *, float *, float *, hipStream_t);
+
 static thread_local char g_err[512] = "";
 
 // ---- per-kernel event profiler -------------------------------------------------------------------------
@@ -209,6 +215,44 @@ int d4gs_blend_bwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy
                    void *stream) {
   return d4gs_blend_bwd_impl(S, n_pixels, C, policy, renders, out, v_out, v_acc, v_renders, v_alphas,
                              (hipStream_t)stream);
+}
+
+int d4gs_pose_encode(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc, void *stream) {
+  if (!R || !T || !enc || r_stride < 3 || t_stride < 1) {
+    d4gs_set_error("pose_encode: NULL buffer or bad stride (r_stride=%d t_stride=%d)", r_stride, t_stride);
+    return D4GS_EINVAL;
+  }
+  return d4gs_pose_encode_impl(R, r_stride, T, t_stride, enc, (hipStream_t)stream);
+}
+
+int d4gs_camera_path_fwd(const float *delta0, const float *delta1, int32_t S, const float *time_params,
+                         int32_t n_time_params, int32_t index, float t, float *RTs, float *jac, float *times,
+                         float *dtimes, float *deltaT, void *stream) {
+  if (S <= 0 || S > 4096) {
+    d4gs_set_error("camera_path: bad S=%d", S);
+    return D4GS_EINVAL;
+  }
+  if (!delta0 || !delta1 || !RTs || !times || !dtimes || !deltaT) {
+    d4gs_set_error("camera_path: NULL buffer");
+    return D4GS_EINVAL;
+  }
+  /* move_model.py:118-131: only interior frames of the per-frame table move the exposure window */
+  int moving = time_params != NULL && index > 0 && index < n_time_params - 1;
+  return d4gs_camera_path_fwd_impl(delta0, delta1, S, time_params, index, t, moving, RTs, jac, times, dtimes, deltaT,
+                                   (hipStream_t)stream);
+}
+
+int d4gs_camera_path_bwd(const float *jac, const float *dtimes, const float *deltaT, const float *v_RTs,
+                         const float *v_times, const float *v_deltaT, int32_t S, int32_t index,
+                         int32_t n_time_params, float *v_delta0, float *v_delta1, float *v_time_params,
+                         void *stream) {
+  if (S <= 0 || n_time_params < 0 || n_time_params > 52 || !jac || !dtimes || !deltaT || !v_delta0 || !v_delta1 ||
+      (n_time_params > 0 && !v_time_params)) {
+    d4gs_set_error("camera_path_bwd: bad arguments (S=%d n_time_params=%d)", S, n_time_params);
+    return D4GS_EINVAL;
+  }
+  return d4gs_camera_path_bwd_impl(jac, dtimes, deltaT, v_RTs, v_times, v_deltaT, S, index, n_time_params, v_delta0,
+                                   v_delta1, v_time_params, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -4,15 +4,21 @@ Mirror of the reference's `MoveModel` (flow3d/models/move_model.py:66-213) and o
 (flow3d/models/utils/spline_utils.py:12-54,177-215,371-408).  Same class / method names, same state_dict keys
 (`RT_main.*`, `RT_head0.*`, `RT_head1.*`, `time_params`), so a reference checkpoint's `move_model` entry loads.
 
-This stays plain PyTorch on purpose ("host-side producer of per-sub-sample inputs"): 30k parameters and
-S<=16 poses per render - latency-only work that feeds the HIP path `times [S]` and `RTs [S,3,4]`.  The pypose ops
-the reference calls (se3.Exp, SE3.Log, SO3 Inv/@/Log, so3.Exp, bvv; pypose==0.6.8 is not installable here) are
+The MLP (30k parameters) stays `nn.Linear`.  Everything after it - se3.Exp of the two heads, lerp/slerp, SE3.Log,
+se3_to_SE3, the exposure-time lerp - and the pose pre-processing + positional embedding before it are latency-only
+work (12 differentiable inputs, 12*S outputs) that eager PyTorch spreads over ~700 forward and ~1500 backward
+launches per render (12.6 ms on MI355X, 3 renders per training step).  On a GPU they run as ONE HIP launch each
+way (`csrc/camera.hip`: dual-number forward that also emits the Jacobian, mat-vec backward; `CameraPathFn` /
+`pose_encode` below) and raise if libd4gs.so is missing.  For CPU tensors the reference-style eager chain below
+runs, exactly as the reference's own device-agnostic module does.  The pypose ops the reference calls (se3.Exp, SE3.Log, SO3 Inv/@/Log, so3.Exp, bvv; pypose==0.6.8 is not installable here) are
 restated in torch below, including the reference's convention quirk: pypose's Log returns [tau, phi] and the
 result is fed to `se3_to_SE3`, which reads it as [w (rotation), u (translation)] (move_model.py:146-147).
 """
 from __future__ import annotations
 
 import math
+
+import ctypes as C
 
 import torch
 import torch.nn as nn
@@ -152,6 +158,62 @@ def _posenc(x, num_freqs=5):
 P_input_ch = 6 * (1 + 2 * 5)  # 66
 
 
+# ------------------------------------------------------------------ fused HIP path (csrc/camera.hip)
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def pose_encode(R, T):
+    """preprocessPose + positional embedding of one pose in one launch: R [3,3] (any row stride), T [3,1] -> [1,66]."""
+    from . import _lib as L
+
+    assert R.is_cuda and R.dtype == torch.float32 and T.dtype == torch.float32 and R.shape == (3, 3)
+    if R.stride(1) != 1:
+        R = R.contiguous()
+    enc = torch.empty(1, P_input_ch, device=R.device, dtype=torch.float32)
+    T = T.reshape(3, -1)[:, 0]
+    L.check(L.lib().d4gs_pose_encode(_p(R), R.stride(0), _p(T), T.stride(0), _p(enc), _stream(R)), "pose_encode")
+    return enc
+
+
+class CameraPathFn(torch.autograd.Function):
+    """(delta0 [1,6], delta1 [1,6], time_params [1,P]) -> RTs [S,3,4], times [1,S], deltaT [1,1]."""
+
+    @staticmethod
+    def forward(ctx, delta0, delta1, time_params, S, index, t, moving):
+        from . import _lib as L
+
+        dev = delta0.device
+        d0, d1 = delta0.detach().contiguous().float(), delta1.detach().contiguous().float()
+        tp = time_params.detach().contiguous().float()
+        buf = torch.empty(S * 12 + S * 144 + 2 * S + 2, device=dev, dtype=torch.float32)
+        RTs, jac, times, dtimes, dT = buf.split([S * 12, S * 144, S, S, 2])
+        L.check(L.lib().d4gs_camera_path_fwd(_p(d0), _p(d1), S, _p(tp if moving else None), tp.numel(), index, float(t),
+                                             _p(RTs), _p(jac), _p(times), _p(dtimes), _p(dT), _stream(d0)),
+                "camera_path_fwd")
+        ctx.save_for_backward(jac, dtimes, dT)
+        ctx.meta = (S, index, tp.numel(), time_params.shape)
+        return RTs.view(S, 3, 4), times.view(1, S), dT[:1].view(1, 1)
+
+    @staticmethod
+    def backward(ctx, v_RTs, v_times, v_dT):
+        from . import _lib as L
+
+        jac, dtimes, dT = ctx.saved_tensors
+        S, index, P, tp_shape = ctx.meta
+        cont = lambda v: None if v is None else v.contiguous().float()
+        v_RTs, v_times, v_dT = cont(v_RTs), cont(v_times), cont(v_dT)
+        out = torch.empty(12 + P, device=jac.device, dtype=torch.float32)
+        L.check(L.lib().d4gs_camera_path_bwd(_p(jac), _p(dtimes), _p(dT), _p(v_RTs), _p(v_times), _p(v_dT), S, index, P,
+                                             _p(out[:6]), _p(out[6:12]), _p(out[12:]), _stream(jac)),
+                "camera_path_bwd")
+        return out[:6].view(1, 6), out[6:12].view(1, 6), out[12:].view(tp_shape), None, None, None, None
+
+
 class MoveModel(nn.Module):
     """move_model.py:66-213 (camera_mode='linear', the only mode the reference instantiates: scene_model.py:36)."""
 
@@ -182,13 +244,19 @@ class MoveModel(nn.Module):
     def postprocessPose(self, RT):
         return se3_to_SE3(RT)
 
+    def _fused(self, R, T):
+        return R.is_cuda and not (R.requires_grad or T.requires_grad) and R.dtype == T.dtype == torch.float32
+
+    def _heads(self, R, T):
+        enc = pose_encode(R, T) if self._fused(R, T) else _posenc(self.preprocessPose(R, T).unsqueeze(0))
+        x = self.RT_main(enc)
+        return self.RT_head0(x), self.RT_head1(x)
+
     def forward(self, R, T, time, stage="second"):
-        RT = self.preprocessPose(R, T).unsqueeze(0)
-        x = self.RT_main(_posenc(RT))
-        detaRT0, detaRT1 = self.RT_head0(x), self.RT_head1(x)
+        detaRT0, detaRT1 = self._heads(R, T)
         if stage == "first":
-            deltaT0 = torch.zeros(1).to(RT.device)
-            deltaT1 = torch.zeros(1).to(RT.device)
+            deltaT0 = torch.zeros(1, device=detaRT0.device)
+            deltaT1 = torch.zeros(1, device=detaRT0.device)
         else:
             index = int(time)
             if index <= 0 or index >= self.time_params.shape[-1] - 1:
@@ -206,6 +274,12 @@ class MoveModel(nn.Module):
 
     def forward_start_end_mid(self, info, num_cameras=10, mode="uniform", stage="second"):
         R, T, time = info["R"], info["T"], info["timestep"]
+        if self._fused(R, T) and num_cameras > 1:
+            d0, d1 = self._heads(R, T)
+            index = int(time)
+            moving = stage != "first" and 0 < index < self.time_params.shape[-1] - 1
+            assert mode == "uniform"  # the only mode the reference calls (scene_model.py:254,272)
+            return CameraPathFn.apply(d0, d1, self.time_params, num_cameras, index, float(time), moving)
         RT_start, RT_end, time_start, time_end = self.forward(R, T, time, stage=stage)
         RTs = self._interpolate(se3_Exp(RT_start), se3_Exp(RT_end), num_cameras=num_cameras, mode=mode)  # [1,S,7]
         RTs = self.postprocessPose(SE3_Log(RTs)).squeeze(0)  # [S,3,4]

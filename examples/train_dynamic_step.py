@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""A stage-2 style training step on the drop-in scene model, on synthetic data.
+
+Mirrors the SHAPE of the reference's `Trainer.train_step` (flow3d/trainer.py:203-274) - three render groups per step
+(static `bg_only` blurry frame, dynamic full blurry frame with mask / track / depth channels, static `mid` frame),
+an L1 photometric loss, one Adam optimizer per parameter tensor, and the densification statistics of
+`_prepare_control_step` - without the reference's data pipeline, PWC-Net / SSIM losses or control steps
+(out of scope).  It exists to show the seam in a real autograd + optimizer loop:
+
+    python examples/train_dynamic_step.py --steps 20
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from deblur4dgs_amd.control import accumulate_from_model  # noqa: E402
+from deblur4dgs_amd.scene_model import GaussianParams, MotionBases, SceneModel  # noqa: E402
+from deblur4dgs_amd.synth import make_scene  # noqa: E402
+
+
+def build(n_fg=40_000, n_bg=100_000, K=20, W=512, H=288, dev="cuda:0", seed=0):
+    """The reference's default scene size (run_training_dynamic.py:118-120): 40 k fg + 100 k bg, 20 bases."""
+    sc = make_scene(n_fg + n_bg, n_fg, K, 1, W, H, seed=seed)
+    keys = ("means", "quats", "scales", "colors", "opacities")
+    fg = GaussianParams(*[sc[k][:n_fg].clone() for k in keys], motion_coefs=sc["motion_coefs"].clone())
+    bg = GaussianParams(*[sc[k][n_fg:].clone() for k in keys])
+    model = SceneModel(sc["K"][None].clone(), sc["viewmat"][None].clone(), fg, MotionBases(sc["rots"], sc["transls"]), bg)
+    return model.to(dev), sc
+
+
+def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, **kw):
+    model, sc = build(W=W, H=H, dev=dev, **kw)
+    w2c, K = sc["viewmat"][None].to(dev), sc["K"][None].to(dev)
+    # targets: renders of a perturbed copy of the scene (so the loss has something to fit)
+    with torch.no_grad():
+        tgt_model, _ = build(W=W, H=H, dev=dev, seed=1, **kw)
+        tgt_dyn = tgt_model.render(3, w2c, K, (W, H), mode="blury")["img"]
+        tgt_sta = tgt_model.render(3, w2c, K, (W, H), bg_only=True, mode="blury")["img"]
+    opts = [torch.optim.Adam([p], lr=lr) for p, lr in
+            [(p, 1.6e-4) for p in (model.fg.params["means"], model.bg.params["means"])] +
+            [(p, 1e-2) for n, p in model.named_parameters() if "colors" in n or "opacities" in n] +
+            [(p, 5e-3) for n, p in model.named_parameters() if "scales" in n or "quats" in n or "motion_coefs" in n] +
+            [(p, 1.6e-4) for p in model.motion_bases.parameters()] +
+            [(p, 5e-4) for p in model.move_model.parameters()]]
+    N = model.num_gaussians
+    stats = {"xys_grad_norm_acc": torch.zeros(N, device=dev), "vis_count": torch.zeros(N, dtype=torch.int64, device=dev),
+             "max_radii": torch.zeros(N, device=dev)}
+    target_ts = torch.tensor([1.0, 2.0, 4.0, 5.0], device=dev)
+    target_w2cs = w2c.expand(4, 4, 4).contiguous()
+    losses = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        out1 = model.render(3, w2c, K, (W, H), bg_only=True, return_depth=True, return_mask=True, mode="blury")
+        out2 = model.render(3, w2c, K, (W, H), target_ts=target_ts, target_w2cs=target_w2cs, return_depth=True,
+                            return_mask=True, mode="blury")  # 17 channels
+        xys2, radii2, wh2 = model._current_xys, model._current_radii, model._current_img_wh
+        out3 = model.render(3, w2c, K, (W, H), bg_only=True, return_depth=True, mode="mid")
+        loss = (out1["img"] - tgt_sta).abs().mean() + (out2["img"] - tgt_dyn).abs().mean() + \
+            0.1 * (out3["img"] - tgt_sta).abs().mean() + 1e-3 * out2["tracks_3d"].square().mean()
+        loss.backward()
+        for o in opts:
+            o.step()
+        model._current_xys, model._current_radii, model._current_img_wh = xys2, radii2, wh2
+        accumulate_from_model(stats, model, batch_size=1)
+        losses.append(float(loss.detach()))
+        if verbose and (it % 5 == 0 or it == steps - 1):
+            print(f"step {it:3d}  loss {losses[-1]:.5f}")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    if verbose:
+        print(f"{1e3 * dt:.2f} ms / step  (3 render groups: 11 + 11 + 1 sub-samples, {N} Gaussians, fwd + bwd + Adam)")
+        print(f"visible-instance count accumulated: {int(stats['vis_count'].sum())}")
+    return losses, stats, dt
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args()
+    train(a.steps)

@@ -194,6 +194,29 @@ int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad /* [S,N,2] */
                        int64_t *vis_count /* [N] */, float *max_radii /* [N] */, int32_t update_max_radii,
                        void *stream);
 
+/* a12 camera path: the generator of `RTs [S,3,4]` / `times [S]` that feed d4gs_project_fwd.
+ * Replaces the eager chain of MoveModel.forward_start_end_mid (flow3d/models/move_model.py:138-166):
+ *   pypose se3.Exp(delta0/1) -> linear_interpolation (flow3d/models/utils/spline_utils.py:371-408) -> SE3.Log ->
+ *   se3_to_SE3 (spline_utils.py:197-215, with the [tau,phi]-read-as-[w,u] convention of move_model.py:146-147), and
+ *   the exposure-time lerp of move_model.py:118-135,151-158 (half-width clamp(relu(time_params[index]),0.1,0.9) on
+ *   interior frames 0 < index < n_time_params-1, else 0; pass time_params = NULL for stage "first").
+ * delta0/delta1 [6] are the two MLP head outputs.  jac [S,12,12] = d RTs[s,i] / d (delta0|delta1)[j] (NULL to skip),
+ * dtimes [S] = d times / d time_params[index], deltaT [2] = {|half-width|, its derivative}.  The backward is the
+ * mat-vec v_delta = v_RTs . jac plus the time_params row (v_* inputs may be NULL = zero). */
+int d4gs_camera_path_fwd(const float *delta0, const float *delta1, int32_t S, const float *time_params,
+                         int32_t n_time_params, int32_t index, float t, float *RTs /* [S,3,4] */,
+                         float *jac /* [S,12,12] */, float *times /* [S] */, float *dtimes /* [S] */,
+                         float *deltaT /* [2] */, void *stream);
+int d4gs_camera_path_bwd(const float *jac, const float *dtimes, const float *deltaT, const float *v_RTs,
+                         const float *v_times, const float *v_deltaT, int32_t S, int32_t index,
+                         int32_t n_time_params, float *v_delta0 /* [6] */, float *v_delta1 /* [6] */,
+                         float *v_time_params /* [n_time_params] */, void *stream);
+/* MoveModel.preprocessPose + positional embedding (move_model.py:12-63,104-110; spline_utils.py:177-195):
+ * R [3,3] with row stride r_stride (4 for the top-left block of a [4,4] w2c), T [3] with element stride t_stride
+ * -> enc [66] = [x, sin(x f), cos(x f)]_{f=1,2,4,8,16}, x = SE3_to_se3([R|T]). */
+int d4gs_pose_encode(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc /* [66] */,
+                     void *stream);
+
 /* a9 exposure blend (scene_model.py:386-397): out = mean_S; policy[c] 1 -> max over {raw_0..raw_{S-2}, mean},
  * 2 -> min over the same set (the reference's in-place quirk); acc = mean_S alphas. */
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] [C] */,

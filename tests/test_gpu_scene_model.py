@@ -139,3 +139,19 @@ def test_control_stats_match_reference_accumulation():
     accumulate_from_model(stats, model, batch_size=2, update_max_radii=True)
     rad = torch.cat(list(model._current_radii), 0).float().amax(0) / max(W, H)
     assert torch.allclose(stats["max_radii"], torch.maximum(before, rad), rtol=1e-6, atol=0)
+
+
+def test_training_loop_example_reduces_the_loss():
+    """examples/train_dynamic_step.py: three render groups (incl. the 17-channel dynamic one), Adam on every leaf,
+    densification statistics - the loss must go down and stay finite."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_dynamic_step.py")
+    spec = importlib.util.spec_from_file_location("train_dynamic_step", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    losses, stats, _ = mod.train(steps=12, W=128, H=96, n_fg=3000, n_bg=5000, K=6, verbose=False)
+    assert all(l == l and l < 1e3 for l in losses)
+    assert losses[-1] < 0.9 * losses[0], losses
+    assert int(stats["vis_count"].sum()) > 0 and float(stats["xys_grad_norm_acc"].sum()) > 0
