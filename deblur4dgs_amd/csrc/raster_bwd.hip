@@ -214,6 +214,8 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
 // and replays only those.  Each wave reduces its row over its 64 lanes (permlane swaps) into its own LDS slab; the
 // four slabs are added in fixed order when the batch is written out - still no atomics, still deterministic.
 // ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int D, bool DEPTH>
 __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
 #pragma clang fp contract(off)
@@ -223,7 +225,18 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   constexpr int R = 6 + NCH;
   constexpr int RP = (R + 1) | 1;
   constexpr int NB = 64;  // splats per batch
+  // With >= 16 colour channels the colour gradients V_c[j] = sum_p vo[c][p] * fac[p][j] of channels 0..15 leave the
+  // VALU: they are a [16 ch x 64 px] x [64 px x 16 hits] product, A = this quadrant's image gradient (fixed for the
+  // whole kernel, 16 registers), B = the hits' `fac` parked in LDS; one v_mfma_f32_16x16x4_f32 per hit replaces 16
+  // multiplies + 16 wave reductions.  The remaining rows (6 moments + channels >= 16, i.e. depth) stay on the VALU.
+  constexpr int MC = D >= 16 ? 16 : 0;        // channels reduced on the matrix pipe
+  constexpr int RV = R - MC;                  // rows reduced on the VALU
+  constexpr int CB = MC ? RV + 1 : 6;         // slab column of channel 0 (VALU rows, their pad slot, then colours)
+  constexpr int FS = 17;                      // fac tile [64 px][16 hits], row stride (bank-conflict padding)
+  static_assert(!MC || CB + MC <= RP, "slab row too short");
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  __shared__ float sfac[MC ? 4 * 64 * FS : 1];
+  __shared__ int shit[MC ? 4 * 16 : 1];
   __shared__ float4 sg0[NB];
   __shared__ float4 sg1[NB];
   __shared__ float4 sbox[NB];
@@ -283,6 +296,39 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   const int hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
   const size_t inst_base = (size_t)s * a.N;
   float *myslab = sgrad + wv * NB * RP;
+  // A fragments (lane l holds A[row = l & 15][k = l >> 4]): channel l & 15 at quadrant pixel 4 kk + (l >> 4)
+  float afrag[MC ? 16 : 1];
+  float *myfac = sfac + (MC ? wv * 64 * FS : 0);
+  int *myhit = shit + (MC ? wv * 16 : 0);
+  int nh = 0;
+  if constexpr (MC > 0) {
+    static_assert(256 * MC <= 4 * NB * RP, "exchange buffer");
+#pragma unroll
+    for (int c = 0; c < MC; c++) sgrad[tid * MC + c] = vo[c];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) afrag[kk] = sgrad[(wv * 64 + 4 * kk + (lane >> 4)) * MC + (lane & 15)];
+  }
+  // nhits parked hits -> colour rows of this wave's slab (C/D layout: col = l & 15 (hit), row = (l >> 4) * 4 + reg)
+  auto flush = [&](int nhits) {
+    if constexpr (MC > 0) {
+      __builtin_amdgcn_wave_barrier();
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // even / odd k-steps, added in fixed order
+      const float *bp = myfac + (lane >> 4) * FS + (lane & 15);
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], bp[4 * kk * FS], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk + 1], bp[(4 * kk + 4) * FS], acc1, 0, 0, 0);
+      }
+      acc0 += acc1;
+      const int n = lane & 15;
+      if (n < nhits) {
+        float *dst = myslab + myhit[n] * RP + CB + (lane >> 4) * 4;
+        dst[0] = acc0[0], dst[1] = acc0[1], dst[2] = acc0[2], dst[3] = acc0[3];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
   // rows behind the tile's last contributor are never replayed: zero them here (no whole-buffer memset needed)
   for (int idx = hi + 1 + tid; idx < end; idx += 256) {
     float *dst = a.isect_grad + (size_t)a.sorted_emit[idx] * R;
@@ -344,7 +390,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         const float ra = __builtin_amdgcn_rcpf(1.f - am);
         T *= ra;
         const float fac = am * T;
-        float row[R];
+        float row[RV];
         float d = 0.f;
 #pragma unroll
         for (int v = 0; v < DV; v++) {
@@ -356,7 +402,11 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         }
         if (DEPTH) d = __builtin_fmaf(vo[D], g0.w, d);
 #pragma unroll
-        for (int c = 0; c < NCH; c++) row[6 + c] = fac * vo[c];
+        for (int c = MC; c < NCH; c++) row[6 + c - MC] = fac * vo[c];
+        if constexpr (MC > 0) {
+          myfac[lane * FS + nh] = fac;
+          if (lane == 0) myhit[nh] = j;
+        }
         const float v_alpha = __builtin_fmaf(T, d, ra * (va - bsum));
         bsum = __builtin_fmaf(fac, d, bsum);
         const bool ok = valid && (ov <= 0.999f);
@@ -370,14 +420,26 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         row[4] = vsy * dy;
         row[5] = vs;
         wave_sum_store(row, myslab + j * RP, lane);
+        if constexpr (MC > 0) {
+          if (++nh == 16) {
+            flush(16);
+            nh = 0;
+          }
+        }
       }
+    }
+    if constexpr (MC > 0) {
+      if (nh) flush(nh);
+      nh = 0;
     }
     __syncthreads();
     if (emit >= 0) {
-      float sum[R];
+      float sum[R];  // back in the row order of isect_grad: 6 moments, then channels 0..NCH-1
 #pragma unroll
-      for (int r = 0; r < R; r++)
-        sum[r] = (sgrad[tid * RP + r] + sgrad[(NB + tid) * RP + r]) + (sgrad[(2 * NB + tid) * RP + r] + sgrad[(3 * NB + tid) * RP + r]);
+      for (int r = 0; r < R; r++) {
+        const int q = !MC || r < 6 ? r : (r - 6 < MC ? CB + r - 6 : r - MC);
+        sum[r] = (sgrad[tid * RP + q] + sgrad[(NB + tid) * RP + q]) + (sgrad[(2 * NB + tid) * RP + q] + sgrad[(3 * NB + tid) * RP + q]);
+      }
       const float4 g1 = sg1[tid];  // conic * log2(e), 1 / opacity
       float *dst = a.isect_grad + (size_t)emit * R;
       dst[0] = (g1.x * sum[0] + g1.y * sum[1]) * LN2;  // dL/dx = a Sum(vs dx) + b Sum(vs dy)
@@ -403,8 +465,6 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
 // the 6 moments into d/dx, d/dy, d/dconic, d/dopacity.  This removes the ~45 % of VALU time variant B spends in
 // cross-lane reductions, and the MFMA pipe runs beside the VALU pipe of the SIMD's other waves.
 // ---------------------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 template <int D, bool DEPTH>
 __global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
 #pragma clang fp contract(off)
