@@ -25,12 +25,20 @@ struct EmitArgs {
   uint64_t *keys;
   int32_t *gid_of_emit;
   int tw, th;
+  const int64_t *n_dev;  // device {total, longest list}: the launch is a no-op when they exceed what the caller sized
+  int64_t cap, max_hint;
 };
+
+// D4gsIsect.n_isect is a CAPACITY: the host may size the lists from a guess and look at the real count afterwards.
+__device__ __forceinline__ bool over_capacity(const int64_t *n_dev, int64_t cap, int64_t max_hint) {
+  return n_dev && (n_dev[0] > cap || (max_hint > 0 && n_dev[1] > max_hint));
+}
 
 __global__ void __launch_bounds__(256) k_emit(const EmitArgs a) {
   // wave w handles 64 consecutive Gaussians of sub-sample (w % S): concurrently resident waves then spread
   // their atomics over all S*tiles cursors instead of the ~tiles cursors of one sub-sample (measured: 4.3 M
   // atomics cost 1.19 ms on 576 addresses vs 0.26 ms on 4608; scripts/microbench/atomics.hip).
+  if (over_capacity(a.n_dev, a.cap, a.max_hint)) return;
   const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int s = (int)(w % a.d.S);
   const int64_t g64 = (w / a.d.S) * 64 + (threadIdx.x & 63);
@@ -143,10 +151,13 @@ struct SortArgs {
   int32_t *sorted_gid;
   int32_t *sorted_emit;
   int lo, cap;  // this launch sorts the lists with lo < n <= cap in LDS; cap < 0: everything longer, in global memory
+  const int64_t *n_dev;
+  int64_t n_cap, max_hint;
 };
 
 __global__ void __launch_bounds__(256) k_tile_sort(const SortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+  if (over_capacity(a.n_dev, a.n_cap, a.max_hint)) return;
   const int t = blockIdx.x;
   const int base = a.tile_offsets[t];
   const int n = a.tile_offsets[t + 1] - base;
@@ -194,6 +205,7 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.gid_of_emit = isect->gid_of_emit;
   e.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
   e.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
+  e.n_dev = proj->n_isect, e.cap = isect->n_isect, e.max_hint = isect->max_tile_count;
   const int64_t n_waves = (int64_t)dims->S * ((dims->N + 63) / 64);
   D4GS_LAUNCH("k_emit", k_emit, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, stream, e);
   int rc = d4gs_check_launch("k_emit");
@@ -211,7 +223,7 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
     const int64_t longest = isect->max_tile_count > 0 ? isect->max_tile_count : isect->n_isect;
     if (c > 0 && longest <= classes[c][0]) break;  // no list is that long
     SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
-               classes[c][0], classes[c][1]};
+               classes[c][0], classes[c][1], proj->n_isect, isect->n_isect, isect->max_tile_count};
     const size_t lds = classes[c][1] > 0 ? (size_t)classes[c][1] * 8 : 0;
     D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(256), lds, stream, s);
   }

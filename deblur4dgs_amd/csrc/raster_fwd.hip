@@ -29,6 +29,8 @@ struct RasterFwdArgs {
   float *alphas;   // [S,H,W]
   int32_t *last_ids;
   float *final_T;
+  const int64_t *n_dev;  // device {total, longest list} vs the capacity the lists were sized for (see binning.hip)
+  int64_t cap, max_hint;
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n_blocks) {
@@ -46,6 +48,7 @@ __global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
   __shared__ float4 sg1[64];
   __shared__ float4 scol[64 * DV];
 
+  if (a.n_dev && (a.n_dev[0] > a.cap || (a.max_hint > 0 && a.n_dev[1] > a.max_hint))) return;
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
   const int t = xcd_remap(blockIdx.x, n_tiles);
@@ -157,6 +160,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
   __shared__ float4 sbox[FB];
   __shared__ float4 scol[FB * DV];
 
+  if (a.n_dev && (a.n_dev[0] > a.cap || (a.max_hint > 0 && a.n_dev[1] > a.max_hint))) return;
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
   const int t = xcd_remap(blockIdx.x, n_tiles);
@@ -288,6 +292,7 @@ int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.ed = dims->depth_mode == D4GS_DEPTH_ED;
   a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
   a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid;
+  a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
 #define D4GS_CASE(DD)                                                   \

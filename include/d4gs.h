@@ -103,8 +103,14 @@ typedef struct D4gsProjOut {
 } D4gsProjOut;
 
 typedef struct D4gsIsect {
-  int64_t n_isect;         /* [host] D4gsProjOut.n_isect[0] */
-  int64_t max_tile_count;  /* [host] D4gsProjOut.n_isect[1] (<= 0: unknown, launch every sort class) */
+  int64_t n_isect;         /* [host] CAPACITY of the four lists below (elements), >= D4gsProjOut.n_isect[0].  The host
+                            * may size them from a guess: every kernel of d4gs_bin_sort / d4gs_raster_fwd compares the
+                            * device-side count with this value and returns at once (outputs untouched) when it does
+                            * not fit, so the caller reads D4gsProjOut.n_isect AFTER launching and re-launches with
+                            * exact sizes in that case - no host sync sits between the projection and the rasterizer.
+                            * d4gs_raster_bwd needs the exact count. */
+  int64_t max_tile_count;  /* [host] upper bound of D4gsProjOut.n_isect[1], checked on the device like n_isect
+                            * (<= 0: unknown, launch every sort class) */
   uint64_t *keys;          /* [n_isect] scratch: (depth bits << 32 | emission index) per tile slot */
   int32_t *gid_of_emit;    /* [n_isect] Gaussian id of each emission index */
   int32_t *sorted_gid;     /* [n_isect] per-tile depth-sorted Gaussian ids (flatten_ids) */

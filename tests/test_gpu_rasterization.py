@@ -277,3 +277,27 @@ def test_channel_counts_padding_and_depth_modes(mode, D):
     assert frac_bad(rc[0].cpu(), ref_c, 1e-4) < 2e-3, rel_err(rc[0].cpu(), ref_c)
     for name in ("means", "opac", "colors"):
         assert frac_bad(tg[name].grad.cpu(), t[name].grad, 1e-3) < 3e-3, (name, rel_err(tg[name].grad.cpu(), t[name].grad))
+
+
+def test_optimistic_list_sizes_relaunch_when_the_guess_is_too_small():
+    """The intersection lists are sized from the previous call's count and checked on the device; a scene that grows
+    past the guess must be relaunched with exact sizes and give the same image as a cold call."""
+    from deblur4dgs_amd import engine
+
+    def run(scale_mul):
+        inp = static_inputs(4000, 160, 96, seed=5, scale_mul=scale_mul)
+        return _run_gpu(inp, 160, 96, "RGB+ED", None)[0].clone()
+
+    engine._SIZE_GUESS.clear()
+    cold_small = run(1.0)
+    engine._SIZE_GUESS.clear()
+    cold_big = run(8.0)                       # many more (tile, splat) intersections
+    engine._SIZE_GUESS.clear()
+    before = engine._SIZE_STATS["relaunched"]
+    assert torch.equal(run(1.0), cold_small)  # cold: exact sizes
+    assert torch.equal(run(1.0), cold_small)  # warm: the guess fits, no relaunch
+    assert engine._SIZE_STATS["relaunched"] == before
+    assert torch.equal(run(8.0), cold_big)    # guess far too small -> device-side guard -> relaunch
+    assert engine._SIZE_STATS["relaunched"] == before + 1
+    assert torch.equal(run(1.0), cold_small)  # guess far too big: fits
+    assert engine._SIZE_STATS["relaunched"] == before + 1
