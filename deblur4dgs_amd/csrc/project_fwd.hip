@@ -10,6 +10,8 @@
 // Work decomposition: one lane per Gaussian g, looping over the S sub-samples, so leaf parameters are read
 // from HBM once and reused S times (coalesced SoA-by-tensor loads: consecutive lanes read consecutive rows).
 // Per-block LDS: the S*K*9 time-blended bases (broadcast reads) and the block's softmaxed coefficients.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -409,7 +411,8 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   }
   const int blocks = (dims->N + D4GS_PROJ_BLOCK - 1) / D4GS_PROJ_BLOCK;
   const size_t hist_bytes = sizeof(int) * 2 * (size_t)a.tw * a.th;
-  a.count_apart = hist_bytes <= 64 * 1024 && dims->N > 0;  // bigger tile grids keep the in-kernel global atomics
+  static const bool force_in_kernel = getenv("D4GS_COUNT_IN_PROJECT") != nullptr;  // test hook for the fallback
+  a.count_apart = hist_bytes <= 64 * 1024 && dims->N > 0 && !force_in_kernel;  // bigger tile grids: in-kernel atomics
   D4GS_LAUNCH("k_project_fwd", k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
   int rc = d4gs_check_launch("k_project_fwd");
   if (rc) return rc;

@@ -301,3 +301,37 @@ def test_optimistic_list_sizes_relaunch_when_the_guess_is_too_small():
     assert engine._SIZE_STATS["relaunched"] == before + 1
     assert torch.equal(run(1.0), cold_small)  # guess far too big: fits
     assert engine._SIZE_STATS["relaunched"] == before + 1
+
+
+def test_tile_counting_paths_agree_and_huge_tile_grids_work():
+    """k_count_tiles (LDS-aggregated ranks, tile grids up to 8192 tiles) and the in-kernel global atomics it replaces
+    (kept for bigger grids; forced here with D4GS_COUNT_IN_PROJECT) must give bit-identical images and gradients:
+    ranks only choose the unsorted slot, the per-tile order comes from the (depth, emission index) sort."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tests.util import static_inputs
+from deblur4dgs_amd.rasterization import rasterization
+outs = []
+for (N, W, H, sm) in ((30000, 320, 200, 2.5), (3000, 2320, 1040, 6.0)):   # 145 x 65 = 9425 tiles > 8192
+    inp = static_inputs(N, W, H, seed=7, dtype=torch.float32, D=3, scale_mul=sm)
+    t = {k: v.cuda() for k, v in inp.items()}
+    t["means"].requires_grad_()
+    rc, ra, info = rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"][None], t["K"][None], W, H,
+                                 render_mode="RGB+ED")
+    (rc * torch.linspace(0, 1, rc.numel(), device="cuda").view_as(rc)).sum().backward()
+    torch.cuda.synchronize()
+    assert info["n_isect"] > 0 and torch.isfinite(rc).all() and float(ra.max()) > 0.5
+    outs += [rc.cpu(), ra.cpu(), info["last_ids"].cpu(), info["flatten_ids"].cpu(), t["means"].grad.cpu()]
+torch.save(outs, sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for env_extra, name in (({}, "/tmp/d4gs_cnt_a.pt"), ({"D4GS_COUNT_IN_PROJECT": "1"}, "/tmp/d4gs_cnt_b.pt")):
+        subprocess.check_call([sys.executable, "-c", code, name], env=dict(os.environ, **env_extra))
+        res.append(torch.load(name))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
