@@ -269,13 +269,153 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant D: variant B's tile / quadrant mapping, but the four 16-lane ROWS of a quadrant-wave are four independent
+// 4x4-pixel rasterizers.  On the headline scene 68 % of the (quadrant, splat) pairs variant B replays light at most
+// 8 of the 64 lanes (scripts/pair_stats.py): splats are small.  Here every wave compacts, per staged batch, one list
+// of staged indices per row (the splats whose tight alpha >= 1/255 box touches that row's 4x4 block; ballot + mbcnt,
+// order preserved) and the rows walk their own lists in lock-step: iteration i composites up to four different splats.
+// Per-pixel arithmetic and order are unchanged -> bit-identical to variants A and B.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
+#pragma clang fp contract(off)
+  constexpr int NCH = D + (DEPTH ? 1 : 0);
+  constexpr int DP = (D + 3) & ~3;
+  constexpr int DV = DP / 4;
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr int FB = 256;  // splats per batch: staged indices fit one byte
+  __shared__ float4 sg0[FB];
+  __shared__ float4 sg1[FB];
+  __shared__ float4 sbox[FB];
+  __shared__ float4 scol[FB * DV];
+  __shared__ unsigned char slist[4 * 4 * FB];  // [wave][row][position]
+
+  if (a.n_dev && (a.n_dev[0] > a.cap || (a.max_hint > 0 && a.n_dev[1] > a.max_hint))) return;
+  const int n_tiles_s = a.tw * a.th;
+  const int n_tiles = a.S * n_tiles_s;
+  const int t = xcd_remap(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
+  const int ty = tl / a.tw, tx = tl - ty * a.tw;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row = lane >> 4, kq = lane & 15;
+  const int qx0 = tx * D4GS_TILE + (wv & 1) * 8, qy0 = ty * D4GS_TILE + (wv >> 1) * 8;
+  const int x = qx0 + (row & 1) * 4 + (kq & 3), y = qy0 + (row >> 1) * 4 + (kq >> 2);
+  const bool inside = x < a.width && y < a.height;
+  const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
+  // pixel-centre extents of the two block columns / block rows of this quadrant
+  const float xl0 = (float)qx0 + 0.5f, xh0 = (float)qx0 + 3.5f, xl1 = (float)qx0 + 4.5f, xh1 = (float)qx0 + 7.5f;
+  const float yl0 = (float)qy0 + 0.5f, yh0 = (float)qy0 + 3.5f, yl1 = (float)qy0 + 4.5f, yh1 = (float)qy0 + 7.5f;
+  unsigned char *wlist = slist + wv * 4 * FB;
+  const unsigned char *mylist = wlist + row * FB;
+
+  float T = 1.f, acc[NCH];
+  int last = 0;
+  bool done = !inside;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) acc[c] = 0.f;
+
+  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
+  const size_t inst_base = (size_t)s * a.N;
+  for (int b = start; b < end; b += FB) {
+    if (__syncthreads_and(done)) break;  // also orders the previous batch's LDS reads before restaging
+    const int idx = b + tid;
+    if (tid < FB && idx < end) {
+      const int gid = a.sorted_gid[idx];
+      const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
+      const float4 q0 = gp[0], q1 = gp[1];
+      sg0[tid] = q0;
+      sg1[tid] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, 0.f);
+      const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
+      const float det = q1.x * q1.z - q1.y * q1.y;
+      const float idet = 1.f / det;
+      float ex = -1.f, ey = -1.f;
+      if (tau > 0.f && det > 0.f) {
+        ex = sqrtf(2.f * tau * q1.z * idet) + 1e-3f;
+        ey = sqrtf(2.f * tau * q1.x * idet) + 1e-3f;
+      }
+      sbox[tid] = ex < 0.f ? make_float4(1e30f, -1e30f, 1e30f, -1e30f) : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
+      const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
+#pragma unroll
+      for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
+    }
+    __syncthreads();
+    const int nb = min(FB, end - b);
+    // ---- per-row lists of this wave's quadrant ----
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // wave-uniform list lengths
+#pragma unroll
+    for (int k = 0; k < FB / 64; k++) {
+      const int jj = k * 64 + lane;
+      bool h0 = false, h1 = false, h2 = false, h3 = false;
+      if (jj < nb) {
+        const float4 bx = sbox[jj];
+        const bool X0 = (bx.x <= xh0) && (bx.y >= xl0), X1 = (bx.x <= xh1) && (bx.y >= xl1);
+        const bool Y0 = (bx.z <= yh0) && (bx.w >= yl0), Y1 = (bx.z <= yh1) && (bx.w >= yl1);
+        h0 = X0 && Y0, h1 = X1 && Y0, h2 = X0 && Y1, h3 = X1 && Y1;
+      }
+      const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+      const unsigned char jb = (unsigned char)jj;
+      if (h0) wlist[0 * FB + c0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = jb;
+      if (h1) wlist[1 * FB + c1 + __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = jb;
+      if (h2) wlist[2 * FB + c2 + __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u))] = jb;
+      if (h3) wlist[3 * FB + c3 + __builtin_amdgcn_mbcnt_hi((unsigned)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m3, 0u))] = jb;
+      c0 += __popcll(m0), c1 += __popcll(m1), c2 += __popcll(m2), c3 += __popcll(m3);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
+    const int imax = max(max(c0, c1), max(c2, c3));
+    for (int i = 0; i < imax; i++) {
+      const bool act = i < cnt;
+      const int j = act ? (int)mylist[i] : 0;
+      const float4 g0 = sg0[j], g1 = sg1[j];
+      const float dx = g0.x - pxf, dy = g0.y - pyf;
+      const float sigma = splat_sigma2(g1, dx, dy);  // sigma * log2(e)
+      const float alpha = fminf(0.999f, g0.z * __builtin_amdgcn_exp2f(-sigma));
+      bool valid = act && !done && (sigma >= 0.f) && (alpha >= (1.f / 255.f));
+      const float nT = T * (1.f - alpha);
+      const bool stop = valid && (nT <= 1e-4f);
+      done = done || stop;
+      valid = valid && !stop;
+      const float vis = valid ? alpha * T : 0.f;
+#pragma unroll
+      for (int v = 0; v < DV; v++) {
+        const float4 c4 = scol[j * DV + v];
+        if (v * 4 < D) acc[v * 4] = __builtin_fmaf(c4.x, vis, acc[v * 4]);
+        if (v * 4 + 1 < D) acc[v * 4 + 1] = __builtin_fmaf(c4.y, vis, acc[v * 4 + 1]);
+        if (v * 4 + 2 < D) acc[v * 4 + 2] = __builtin_fmaf(c4.z, vis, acc[v * 4 + 2]);
+        if (v * 4 + 3 < D) acc[v * 4 + 3] = __builtin_fmaf(c4.w, vis, acc[v * 4 + 3]);
+      }
+      if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
+      T = valid ? nT : T;
+      last = valid ? (b + j) : last;
+      if ((i & 15) == 15 && __all(done)) break;
+    }
+  }
+
+  if (inside) {
+    const size_t pix = ((size_t)s * a.height + y) * a.width + x;
+    const float al = 1.f - T;
+    a.alphas[pix] = al;
+    a.final_T[pix] = T;
+    a.last_ids[pix] = last;
+    float *o = a.out + pix * NCH;
+#pragma unroll
+    for (int c = 0; c < D; c++) o[c] = acc[c] + (a.background ? T * a.background[c] : 0.f);
+    if (DEPTH) o[D] = a.ed ? acc[D] / fmaxf(al, 1e-10f) : acc[D];
+  }
+}
+
 template <int D, bool DEPTH>
 int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
   static const bool wave_per_tile = getenv("D4GS_FWD_WAVE_PER_TILE") != nullptr;  // variant A, kept for A/B tests
+  static const bool quads = getenv("D4GS_FWD_QUADS") != nullptr;  // variant B
   if (wave_per_tile)
     D4GS_LAUNCH("k_raster_fwd", (k_raster_fwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+  else if (!quads)
+    D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
   else
     D4GS_LAUNCH("k_raster_fwd_q", (k_raster_fwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
   return d4gs_check_launch("k_raster_fwd");

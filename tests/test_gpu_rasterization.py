@@ -203,12 +203,15 @@ torch.cuda.synchronize()
 torch.save((rc.cpu(), ra.cpu(), info["last_ids"].cpu()), sys.argv[1])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env_extra, name in (({}, "/tmp/d4gs_fwd_b.pt"), ({"D4GS_FWD_WAVE_PER_TILE": "1"}, "/tmp/d4gs_fwd_a.pt")):
-        env = dict(os.environ, **env_extra)
+    for env_extra, name in (({}, "/tmp/d4gs_fwd_b.pt"), ({"D4GS_FWD_WAVE_PER_TILE": "1"}, "/tmp/d4gs_fwd_a.pt"),
+                            ({"D4GS_FWD_ROWS": "1"}, "/tmp/d4gs_fwd_d.pt"), ({"D4GS_FWD_QUADS": "1"}, "/tmp/d4gs_fwd_q.pt")):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("D4GS_FWD_")}
+        env.update(env_extra)
         subprocess.check_call([sys.executable, "-c", code, name], env=env)
         outs.append(torch.load(name))
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("scale_mul,radius_clip,near,far", [(40.0, 0.0, 0.01, 1e10), (3.0, 4.0, 0.01, 1e10),
