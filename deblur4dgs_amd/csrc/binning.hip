@@ -112,14 +112,67 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
   return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
+// Lane exchanges of the in-chunk bitonic steps.  `lane ^ M` for M = 1, 2, 3 (quad_perm), 7 (row_half_mirror), 15
+// (row_mirror) is one DPP move on the VALU crossbar; 4 = 3 then 7 and 8 = 7 then 15 are two.  Only the exchanges that
+// cross 16-lane rows (16, 31, 32, 63) go through ds_bpermute, i.e. the CU-wide LDS pipe that bounded this kernel.
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, false);        // [1,0,3,2]
+  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, false);   // [2,3,0,1]
+  else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xf, 0xf, false);   // [3,2,1,0]
+  else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, false); // row_mirror
+  else if constexpr (M == 4) return lane_xor<7>(lane_xor<3>(v));
+  else if constexpr (M == 8) return lane_xor<15>(lane_xor<7>(v));
+  else return (uint32_t)__shfl_xor((int)v, M);
+}
+// compare-exchange with lane ^ M; lanes whose bit BIT is clear keep the smaller key
+template <int M, int BIT>
+__device__ __forceinline__ void lane_cex(uint64_t &v, int lane) {
+  const uint32_t lo = lane_xor<M>((uint32_t)v), hi = lane_xor<M>((uint32_t)(v >> 32));
+  const uint64_t o = ((uint64_t)hi << 32) | lo;
+  const bool lower = (lane & BIT) == 0;
+  v = (lower == (v < o)) ? v : o;
+}
+template <int J, int NV>
+__device__ __forceinline__ void chunk_plain(uint64_t (&v)[NV], int lane) {  // steps J, J/2, .., 1
+  if constexpr (J >= 1) {
+#pragma unroll
+    for (int u = 0; u < NV; u++) lane_cex<J, J>(v[u], lane);
+    chunk_plain<J / 2, NV>(v, lane);
+  }
+}
+template <int K, int NV>
+__device__ __forceinline__ void chunk_block(uint64_t (&v)[NV], int lane) {  // the whole k-block K <= 64 of the network
+#pragma unroll
+  for (int u = 0; u < NV; u++) lane_cex<K - 1, K / 2>(v[u], lane);  // flip step
+  chunk_plain<K / 4, NV>(v, lane);
+}
+
 // LDS form.  `key[0..P)` holds the list padded with UINT64_MAX to a power of two P >= 64.  All steps whose partner
-// distance is < 64 run inside one wave on a 64-key chunk held in registers (xor-shuffles, no LDS traffic, no
-// workgroup barrier); only the steps with distance >= 64 go through LDS with a barrier each.
+// distance is < 64 run inside one wave on 64-key chunks held in registers - four chunks per wave at a time, so the
+// exchange latencies overlap - and the k-blocks 2..64 run back to back without touching LDS; only the steps with
+// distance >= 64 go through LDS with a barrier each.
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t *key, int P) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int k = 2; k <= P; k <<= 1) {
-    int j = k >> 1;
-    for (; j >= 64; j >>= 1) {  // cross-chunk steps
+  const int nchunks = P >> 6;
+  for (int c0 = wv; c0 < nchunks; c0 += 4 * nw) {
+    uint64_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = (c0 + u * nw < nchunks) ? key[(c0 + u * nw) * 64 + lane] : ~0ull;
+    chunk_block<2, 4>(v, lane);
+    chunk_block<4, 4>(v, lane);
+    chunk_block<8, 4>(v, lane);
+    chunk_block<16, 4>(v, lane);
+    chunk_block<32, 4>(v, lane);
+    chunk_block<64, 4>(v, lane);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (c0 + u * nw < nchunks) key[(c0 + u * nw) * 64 + lane] = v[u];
+  }
+  __syncthreads();
+  for (int k = 128; k <= P; k <<= 1) {
+    for (int j = k >> 1; j >= 64; j >>= 1) {  // cross-chunk steps
       for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
         const int blk = t / j, off = t - blk * j;
         const int i = blk * 2 * j + off;
@@ -129,16 +182,14 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t *key, int P) {
       }
       __syncthreads();
     }
-    // in-chunk steps j = min(k/2, 32) .. 1 on registers
-    for (int c = wv; c < (P >> 6); c += nw) {
-      uint64_t v = key[c * 64 + lane];
-      for (int jj = j; jj > 0; jj >>= 1) {
-        const int m = (jj == (k >> 1)) ? (k - 1) : jj;  // flip step of this k-block, else plain distance
-        const uint64_t o = shfl_xor_u64(v, m);
-        const bool lower = (lane & jj) == 0;  // for the flip mask k-1 the top set bit is jj as well
-        v = (lower == (v < o)) ? v : o;       // lower index keeps the min, upper the max
-      }
-      key[c * 64 + lane] = v;
+    for (int c0 = wv; c0 < nchunks; c0 += 4 * nw) {  // distances 32 .. 1
+      uint64_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = (c0 + u * nw < nchunks) ? key[(c0 + u * nw) * 64 + lane] : ~0ull;
+      chunk_plain<32, 4>(v, lane);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (c0 + u * nw < nchunks) key[(c0 + u * nw) * 64 + lane] = v[u];
     }
     __syncthreads();
   }
