@@ -721,36 +721,66 @@ struct GatherArgs {
   float *v_means2d, *v_conics, *v_depths, *v_opac_act, *v_ctab;
 };
 
+// The rows of the 64 instances a wave owns (same sub-sample, consecutive Gaussians) form ONE contiguous span of
+// isect_grad: the wave streams it into LDS with coalesced loads and every lane then sums its own rows from there, in
+// the same k order as a direct read (bit-identical).  Spans longer than the LDS budget (wide splats) are read directly.
+constexpr int GATHER_THREADS = 128, GATHER_ROWS = 192;  // rows of LDS per wave
 template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) k_gather(const GatherArgs a) {
+__global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int R = 6 + NCH;
+  __shared__ float stage[(GATHER_THREADS / 64) * GATHER_ROWS * R];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= a.N) return;
+  const bool in = g < a.N;
+  float *mine = stage + wv * GATHER_ROWS * R;
   float vo = 0.f, vc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) vc[c] = 0.f;
   for (int s = 0; s < a.S; s++) {
-    const size_t i = (size_t)s * a.N + g;
-    const int cnt = a.tiles_touched[i];
+    const size_t i = (size_t)s * a.N + (in ? g : a.N - 1);
+    const int cnt = in ? a.tiles_touched[i] : 0;
+    const int off = a.isect_offsets[i];
+    // span of the wave: [first lane's offset, last lane's offset + count)
+    const int base = __builtin_amdgcn_readfirstlane(off);
+    int endl = off + cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) endl = max(endl, __shfl_xor(endl, o));
+    const int rows = endl - base;
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.f;
-    const float *row = a.isect_grad + (size_t)a.isect_offsets[i] * R;
-    for (int k = 0; k < cnt; k++, row += R) {
+    if (rows <= GATHER_ROWS) {
+      const float *src = a.isect_grad + (size_t)base * R;
+      const int nf = rows * R;
+      for (int f = lane; f < nf; f += 64) mine[f] = src[f];
+      __builtin_amdgcn_wave_barrier();
+      const float *row = mine + (off - base) * R;
+      for (int k = 0; k < cnt; k++, row += R) {
 #pragma unroll
-      for (int r = 0; r < R; r++) acc[r] += row[r];
+        for (int r = 0; r < R; r++) acc[r] += row[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      const float *row = a.isect_grad + (size_t)off * R;
+      for (int k = 0; k < cnt; k++, row += R) {
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] += row[r];
+      }
     }
-    *reinterpret_cast<float2 *>(a.v_means2d + i * 2) = make_float2(acc[0], acc[1]);
-    a.v_conics[i * 3] = acc[2];
-    a.v_conics[i * 3 + 1] = acc[3];
-    a.v_conics[i * 3 + 2] = acc[4];
+    if (in) {
+      *reinterpret_cast<float2 *>(a.v_means2d + i * 2) = make_float2(acc[0], acc[1]);
+      a.v_conics[i * 3] = acc[2];
+      a.v_conics[i * 3 + 1] = acc[3];
+      a.v_conics[i * 3 + 2] = acc[4];
+      a.v_depths[i] = DEPTH ? acc[6 + (DEPTH ? D : 0)] : 0.f;
+    }
     vo += acc[5];
 #pragma unroll
     for (int c = 0; c < D; c++) vc[c] += acc[6 + c];
-    a.v_depths[i] = DEPTH ? acc[6 + (DEPTH ? D : 0)] : 0.f;
   }
+  if (!in) return;
   a.v_opac_act[g] = vo;
 #pragma unroll
   for (int c = 0; c < DP; c++) a.v_ctab[(size_t)g * DP + c] = c < D ? vc[c < D ? c : 0] : 0.f;
@@ -782,7 +812,7 @@ int launch_bwd(const RasterBwdArgs &a, const GatherArgs &ga, int64_t n_isect, hi
     int rc = d4gs_check_launch("k_raster_bwd");
     if (rc) return rc;
   }
-  D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH>), dim3((ga.N + 255) / 256), dim3(256), 0, stream, ga);
+  D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH>), dim3((ga.N + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, stream, ga);
   return d4gs_check_launch("k_gather");
 }
 
