@@ -15,7 +15,7 @@ namespace {
 
 struct EmitArgs {
   D4gsDims d;
-  const float *geom;
+  const float *depths;
   const int32_t *tile_rects;
   const int32_t *tile_ranks;
   const int32_t *tiles_touched;
@@ -34,52 +34,53 @@ __device__ __forceinline__ bool over_capacity(const int64_t *n_dev, int64_t cap,
   return n_dev && (n_dev[0] > cap || (max_hint > 0 && n_dev[1] > max_hint));
 }
 
-__global__ void __launch_bounds__(256) k_emit(const EmitArgs a) {
-  // wave w handles 64 consecutive Gaussians of sub-sample (w % S): concurrently resident waves then spread
-  // their atomics over all S*tiles cursors instead of the ~tiles cursors of one sub-sample (measured: 4.3 M
-  // atomics cost 1.19 ms on 576 addresses vs 0.26 ms on 4608; scripts/microbench/atomics.hip).
+// Block b takes the same 4096 instances of sub-sample b % S as k_count_tiles' block b (1024 lanes x 4): the ranks it
+// hands out per tile are consecutive inside such a chunk, so the 8-byte key stores of one block fall into short
+// contiguous runs of every tile list and merge in that XCD's L2 instead of reaching memory as partial lines.
+constexpr int EMIT_THREADS = 1024, EMIT_PER_THREAD = 4;
+__global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
   if (over_capacity(a.n_dev, a.cap, a.max_hint)) return;
-  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int s = (int)(w % a.d.S);
-  const int64_t g64 = (w / a.d.S) * 64 + (threadIdx.x & 63);
-  if (g64 >= a.d.N) return;
-  const int g = (int)g64;
-  const int64_t i = (int64_t)s * a.d.N + g;
-  const int cnt = a.tiles_touched[i];
-  if (cnt == 0) return;
-  const float4 g0 = *reinterpret_cast<const float4 *>(a.geom + i * D4GS_GEOM_STRIDE);
-  const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
-  const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-  const uint64_t hi = (uint64_t)__float_as_uint(g0.w) << 32;
-  uint32_t e = (uint32_t)a.isect_offsets[i];
+  const int s = blockIdx.x % a.d.S, chunk = blockIdx.x / a.d.S;
   const int tbase = s * a.tw * a.th;
   const int n_tiles_all = a.d.S * a.tw * a.th;
-  if (cnt <= D4GS_RANK_SLOTS) {  // ranks came out of the counting pass: no atomics here
-    const int4 *rp = reinterpret_cast<const int4 *>(a.tile_ranks + i * D4GS_RANK_SLOTS);
-    const int4 rk = rp[0];
-    int4 rk2 = make_int4(0, 0, 0, 0);
-    if (cnt > 4) rk2 = rp[1];
-    const int r[8] = {rk.x, rk.y, rk.z, rk.w, rk2.x, rk2.y, rk2.z, rk2.w};
-    const int w = x1 - x0;
+#pragma unroll 1
+  for (int q = 0; q < EMIT_PER_THREAD; q++) {
+    const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + threadIdx.x;
+    if (g >= a.d.N) continue;
+    const int64_t i = (int64_t)s * a.d.N + g;
+    const int cnt = a.tiles_touched[i];
+    if (cnt == 0) continue;
+    const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
+    const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+    const uint64_t hi = (uint64_t)__float_as_uint(a.depths[i]) << 32;
+    uint32_t e = (uint32_t)a.isect_offsets[i];
+    if (cnt <= D4GS_RANK_SLOTS) {  // ranks came out of the counting pass: no atomics here
+      const int4 *rp = reinterpret_cast<const int4 *>(a.tile_ranks + i * D4GS_RANK_SLOTS);
+      const int4 rk = rp[0];
+      int4 rk2 = make_int4(0, 0, 0, 0);
+      if (cnt > 4) rk2 = rp[1];
+      const int r[8] = {rk.x, rk.y, rk.z, rk.w, rk2.x, rk2.y, rk2.z, rk2.w};
+      const int w = x1 - x0;
 #pragma unroll
-    for (int k = 0; k < D4GS_RANK_SLOTS; k++)
-      if (k < cnt) {
-        const int t = tbase + (y0 + k / w) * a.tw + x0 + k % w;
-        const int slot = a.tile_offsets[t] + r[k];
-        a.keys[slot] = hi | (e + k);
-        a.gid_of_emit[e + k] = g;
-      }
-    return;
-  }
-  for (int ty = y0; ty < y1; ty++)
-    for (int tx = x0; tx < x1; tx++) {
-      const int t = tbase + ty * a.tw + tx;
-      // wide splats sit behind the rank-carrying ones in the (unsorted) tile segment
-      const int slot = a.tile_offsets[t] + a.tile_cursor[t] + atomicSub(a.tile_cursor + n_tiles_all + t, 1) - 1;
-      a.keys[slot] = hi | e;
-      a.gid_of_emit[e] = g;
-      e++;
+      for (int k = 0; k < D4GS_RANK_SLOTS; k++)
+        if (k < cnt) {
+          const int t = tbase + (y0 + k / w) * a.tw + x0 + k % w;
+          const int slot = a.tile_offsets[t] + r[k];
+          a.keys[slot] = hi | (e + k);
+          a.gid_of_emit[e + k] = g;
+        }
+      continue;
     }
+    for (int ty = y0; ty < y1; ty++)
+      for (int tx = x0; tx < x1; tx++) {
+        const int t = tbase + ty * a.tw + tx;
+        // wide splats sit behind the rank-carrying ones in the (unsorted) tile segment
+        const int slot = a.tile_offsets[t] + a.tile_cursor[t] + atomicSub(a.tile_cursor + n_tiles_all + t, 1) - 1;
+        a.keys[slot] = hi | e;
+        a.gid_of_emit[e] = g;
+        e++;
+      }
+  }
 }
 
 // all-ascending bitonic network on `n` keys (any n): step (k, j) compares i with its partner l > i.
@@ -245,7 +246,7 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   }
   EmitArgs e;
   e.d = *dims;
-  e.geom = proj->geom;
+  e.depths = proj->depths;
   e.tile_rects = proj->tile_rects;
   e.tile_ranks = proj->tile_ranks;
   e.tiles_touched = proj->tiles_touched;
@@ -257,8 +258,8 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
   e.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   e.n_dev = proj->n_isect, e.cap = isect->n_isect, e.max_hint = isect->max_tile_count;
-  const int64_t n_waves = (int64_t)dims->S * ((dims->N + 63) / 64);
-  D4GS_LAUNCH("k_emit", k_emit, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, stream, e);
+  const int per_block = EMIT_THREADS * EMIT_PER_THREAD;
+  D4GS_LAUNCH("k_emit", k_emit, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS), 0, stream, e);
   int rc = d4gs_check_launch("k_emit");
   if (rc) return rc;
   const int n_tiles = dims->S * e.tw * e.th;
