@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
   float *cf = Bs + nBs;              // [BLK][KP]   softmaxed coefficients
   float *vcf = cf + BLK * KP;        // [BLK][KP]   their gradients, summed over s
   float *sv = vcf + BLK * KP;        // [BLK][NV]   per-s vectors to be column-reduced
-  float *psum = sv + BLK * NV;       // [4][9K+12]  per-wave segment sums
+  float *psum = sv + BLK * NV;       // [4][9K+13]  per-wave segment sums (+ dump slot)
   const int tid = threadIdx.x;
   const int g = blockIdx.x * BLK + tid;
   const Cam cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
@@ -305,35 +305,37 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
         for (int r = 0; r < 9; r++) v_Rq[r] += vRm[r];
       }
     }
-    // ---- block column sums for sub-sample s: S*(9K) weighted by cf, 12 plain ----
+    // ---- block column sums for sub-sample s: 9K weighted by cf, 12 plain ----
+    // Every wave reduces its 64 lanes with the permlane-swap ladder (common.h) and leaves its totals in its own
+    // psum segment; the 4 segments are then added in fixed order -> deterministic.  (The first version walked the 256
+    // per-thread vectors through LDS: 2 LDS reads per term, 25 % of the kernel.)
     if (dyn || a.in.RTs) {
-      __syncthreads();
+      const int nk = dyn ? K * 9 : 0, no = nk + 12, nop = no + 1;  // +1: wave_sum_store's dump slot
+      const int lane = tid & 63, seg = tid >> 6;
+      float *mine = psum + seg * nop;
+      __syncthreads();  // the previous sub-sample's psum has been consumed
+      if (dyn) {
+        if (dyn_block) {
+          for (int k = 0; k < K; k++) {
+            const float c = cf[tid * KP + k];
+            float p[9];
 #pragma unroll
-      for (int r = 0; r < NV; r++) sv[tid * NV + r] = vec[r];
-      __syncthreads();
-      const int nk = dyn ? K * 9 : 0, no = nk + 12;
-      // (output o, segment) tasks: wave `seg` sums t in [64 seg, 64 seg + 64) for outputs lane, lane + 64, ...;
-      // the 4 segment sums are then added in fixed order -> deterministic, and 4x shorter dependent chains
-      const int seg = tid >> 6, t0 = seg * 64;
-      for (int o = tid & 63; o < no; o += 64) {
-        float a0 = 0.f, a1 = 0.f;
-        if (o < nk) {
-          if (dyn_block) {
-            const int k = o / 9, j = o - k * 9;
-            for (int t = t0; t < t0 + 64; t += 2) {
-              a0 += cf[t * KP + k] * sv[t * NV + j];
-              a1 += cf[(t + 1) * KP + k] * sv[(t + 1) * NV + j];
-            }
+            for (int jj = 0; jj < 9; jj++) p[jj] = c * vec[jj];
+            wave_sum_store(p, mine + k * 9, lane);
           }
         } else {
-          const int r = 9 + (o - nk);
-          for (int t = t0; t < t0 + 64; t += 2) a0 += sv[t * NV + r], a1 += sv[(t + 1) * NV + r];
+          for (int o = lane; o < nk; o += 64) mine[o] = 0.f;
         }
-        psum[seg * no + o] = a0 + a1;
+      }
+      {
+        float q[12];
+#pragma unroll
+        for (int r = 0; r < 12; r++) q[r] = vec[9 + r];
+        wave_sum_store(q, mine + nk, lane);
       }
       __syncthreads();
       for (int o = tid; o < no; o += BLK)
-        part[s * no + o] = (psum[o] + psum[no + o]) + (psum[2 * no + o] + psum[3 * no + o]);
+        part[s * no + o] = (psum[o] + psum[nop + o]) + (psum[2 * nop + o] + psum[3 * nop + o]);
     }
   }
 
@@ -503,7 +505,7 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   const int K = dims->G > 0 ? dims->K : 0;
   const int KP = K | 1;
   size_t lds = sizeof(float) * ((((size_t)dims->S * K * 9 + 3) & ~(size_t)3) + 2 * (size_t)BLK * KP + (size_t)BLK * NV +
-                                4 * ((size_t)K * 9 + 12));
+                                4 * ((size_t)K * 9 + 13));
   if (lds > 160 * 1024) {
     d4gs_set_error("project_bwd: LDS budget exceeded (S=%d K=%d)", dims->S, dims->K);
     return D4GS_EINVAL;
