@@ -46,6 +46,18 @@ class RasterGrads(C.Structure):
                                  "v_depths", "v_opac_act", "v_ctab")]
 
 
+class MoveModelParams(C.Structure):
+    _fields_ = [("w", F * 9), ("b", F * 9), ("time_params", F), ("n_time_params", C.c_int32)]
+
+
+class MoveModelOut(C.Structure):
+    _fields_ = [(n, F) for n in ("enc", "acts", "delta", "RTs", "jac", "times", "dtimes", "deltaT")]
+
+
+class MoveModelGrads(C.Structure):
+    _fields_ = [("v_w", F * 9), ("v_b", F * 9), ("v_time_params", F), ("v_delta", F)]
+
+
 class LeafGrads(C.Structure):
     _fields_ = [(n, F) for n in ("v_means", "v_quats", "v_scales", "v_opacities", "v_colors", "v_motion_coefs",
                                  "v_rots", "v_transls", "v_times", "v_RTs", "v_viewmat", "partials")]
@@ -60,7 +72,7 @@ EXPORTS = (
     "d4gs_version", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
     "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_control_stats", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
-    "d4gs_pose_encode", "d4gs_profile_enable", "d4gs_profile_collect",
+    "d4gs_pose_encode", "d4gs_move_model_fwd", "d4gs_move_model_bwd", "d4gs_profile_enable", "d4gs_profile_collect",
 )
 
 _lib = None
@@ -96,6 +108,10 @@ def lib() -> C.CDLL:
         L.d4gs_camera_path_fwd.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_float, vp, vp, vp, vp, vp, vp]
         L.d4gs_camera_path_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.d4gs_pose_encode.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp]
+        L.d4gs_move_model_fwd.argtypes = [vp, C.c_int32, vp, C.c_int32, P(MoveModelParams), C.c_int32, C.c_int32, C.c_float,
+                                          C.c_int32, P(MoveModelOut), vp]
+        L.d4gs_move_model_bwd.argtypes = [P(MoveModelParams), P(MoveModelOut), vp, vp, vp, C.c_int32, C.c_int32,
+                                          P(MoveModelGrads), vp]
         L.d4gs_blend_fwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp]
         L.d4gs_blend_bwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp, vp, vp]
         if L.d4gs_version() != 100:

@@ -281,6 +281,97 @@ __global__ void k_pose_encode(const float *__restrict__ Rp, int r_stride, const 
     }
 }
 
+// ---- the MoveModel MLP (move_model.py:66-110): 66 -> 64 x4 (LeakyReLU 0.01) -> 64, two heads 64 -> 64 -> 6 ---------
+// 30 k parameters, batch 1: in eager PyTorch 9 GEMV launches forward and ~30 backward per render.  One block here.
+// Layer order everywhere: main.0, main.2, main.4, main.6, main.8, head0.0, head0.2, head1.0, head1.2.
+// acts: x0[66] a1[64] a2[64] a3[64] a4[64] m[64] ua[64] wa[64]  (post-activation inputs of every layer)
+constexpr int MLP_IN = 66, MLP_W = 64, MLP_ACTS = MLP_IN + 7 * MLP_W;
+constexpr float MLP_SLOPE = 0.01f;
+
+// y[0..out) = act(b + W x); 4 lanes per output (quad reduction), 256 threads
+__device__ __forceinline__ void mlp_layer(const float *__restrict__ W, const float *__restrict__ b, const float *x, int in,
+                                          int out, bool act, float *y) {
+  const int j = threadIdx.x >> 2, q = threadIdx.x & 3;
+  float acc = 0.f;
+  if (j < out)
+    for (int i = q; i < in; i += 4) acc = __builtin_fmaf(W[j * in + i], x[i], acc);
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  if (j < out && q == 0) {
+    float v = acc + b[j];
+    y[j] = act ? (v > 0.f ? v : MLP_SLOPE * v) : v;
+  }
+  __syncthreads();
+}
+
+struct MlpPtrs {
+  const float *w[9];
+  const float *b[9];
+};
+struct MlpGradPtrs {
+  float *w[9];
+  float *b[9];
+};
+
+__global__ void __launch_bounds__(256) k_move_mlp_fwd(const float *__restrict__ enc, MlpPtrs p, float *__restrict__ acts,
+                                                      float *__restrict__ delta0, float *__restrict__ delta1) {
+  __shared__ float sx[MLP_ACTS];
+  __shared__ float sd[12];
+  for (int i = threadIdx.x; i < MLP_IN; i += 256) sx[i] = enc[i];
+  __syncthreads();
+  float *a1 = sx + MLP_IN, *a2 = a1 + 64, *a3 = a2 + 64, *a4 = a3 + 64, *m = a4 + 64, *ua = m + 64, *wa = ua + 64;
+  mlp_layer(p.w[0], p.b[0], sx, MLP_IN, 64, true, a1);
+  mlp_layer(p.w[1], p.b[1], a1, 64, 64, true, a2);
+  mlp_layer(p.w[2], p.b[2], a2, 64, 64, true, a3);
+  mlp_layer(p.w[3], p.b[3], a3, 64, 64, true, a4);
+  mlp_layer(p.w[4], p.b[4], a4, 64, 64, false, m);
+  mlp_layer(p.w[5], p.b[5], m, 64, 64, true, ua);
+  mlp_layer(p.w[7], p.b[7], m, 64, 64, true, wa);
+  mlp_layer(p.w[6], p.b[6], ua, 64, 6, false, sd);
+  mlp_layer(p.w[8], p.b[8], wa, 64, 6, false, sd + 6);
+  for (int i = threadIdx.x; i < MLP_ACTS; i += 256) acts[i] = sx[i];
+  if (threadIdx.x < 6) delta0[threadIdx.x] = sd[threadIdx.x];
+  else if (threadIdx.x < 12) delta1[threadIdx.x - 6] = sd[threadIdx.x];
+}
+
+// one layer of the backward: gW = vz (x) x, gb = vz, vx = W^T vz (then times the LeakyReLU slope of x's layer)
+__device__ __forceinline__ void mlp_layer_bwd(const float *__restrict__ W, const float *vz, const float *x, int in, int out,
+                                              float *__restrict__ gW, float *__restrict__ gb, float *vx, bool add_vx,
+                                              bool x_is_act) {
+  for (int idx = threadIdx.x; idx < in * out; idx += 256) gW[idx] = vz[idx / in] * x[idx % in];
+  if (threadIdx.x < out) gb[threadIdx.x] = vz[threadIdx.x];
+  if (vx && threadIdx.x < in) {
+    const int i = threadIdx.x;
+    float acc = 0.f;
+    for (int j = 0; j < out; j++) acc = __builtin_fmaf(W[j * in + i], vz[j], acc);
+    if (x_is_act) acc *= x[i] > 0.f ? 1.f : MLP_SLOPE;  // a > 0 <=> z > 0
+    vx[i] = add_vx ? vx[i] + acc : acc;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_move_mlp_bwd(const float *__restrict__ acts, MlpPtrs p, const float *__restrict__ v_delta0,
+                                                      const float *__restrict__ v_delta1, MlpGradPtrs g) {
+  __shared__ float sx[MLP_ACTS];
+  __shared__ float va[64], vb[64], vd[12];
+  for (int i = threadIdx.x; i < MLP_ACTS; i += 256) sx[i] = acts[i];
+  if (threadIdx.x < 6) vd[threadIdx.x] = v_delta0[threadIdx.x];
+  else if (threadIdx.x < 12) vd[threadIdx.x] = v_delta1[threadIdx.x - 6];
+  __syncthreads();
+  const float *a1 = sx + MLP_IN, *a2 = a1 + 64, *a3 = a2 + 64, *a4 = a3 + 64, *m = a4 + 64, *ua = m + 64, *wa = ua + 64;
+  // heads: vd -> v_u (va) -> v_m (vb), then vd+6 -> v_w (va) -> v_m += 
+  mlp_layer_bwd(p.w[6], vd, ua, 64, 6, g.w[6], g.b[6], va, false, true);
+  mlp_layer_bwd(p.w[5], va, m, 64, 64, g.w[5], g.b[5], vb, false, false);
+  mlp_layer_bwd(p.w[8], vd + 6, wa, 64, 6, g.w[8], g.b[8], va, false, true);
+  mlp_layer_bwd(p.w[7], va, m, 64, 64, g.w[7], g.b[7], vb, true, false);
+  // trunk: v_z5 = vb
+  mlp_layer_bwd(p.w[4], vb, a4, 64, 64, g.w[4], g.b[4], va, false, true);
+  mlp_layer_bwd(p.w[3], va, a3, 64, 64, g.w[3], g.b[3], vb, false, true);
+  mlp_layer_bwd(p.w[2], vb, a2, 64, 64, g.w[2], g.b[2], va, false, true);
+  mlp_layer_bwd(p.w[1], va, a1, 64, 64, g.w[1], g.b[1], vb, false, true);
+  mlp_layer_bwd(p.w[0], vb, sx, MLP_IN, 64, g.w[0], g.b[0], nullptr, false, false);
+}
+
 }  // namespace
 
 int d4gs_pose_encode_impl(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc,
@@ -308,4 +399,37 @@ int d4gs_camera_path_bwd_impl(const float *jac, const float *dtimes, const float
   k_camera_path_bwd<<<1, 64, 0, stream>>>(jac, dtimes, deltaT, v_RTs, v_times, v_deltaT, S, index, n_time_params,
                                           v_delta0, v_delta1, v_time_params);
   return d4gs_check_launch("k_camera_path_bwd");
+}
+
+int d4gs_move_model_fwd_impl(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const float *const *w,
+                             const float *const *b, int32_t S, const float *time_params, int32_t index, float t,
+                             int32_t moving, float *enc, float *acts, float *delta, float *RTs, float *jac, float *times,
+                             float *dtimes, float *deltaT, hipStream_t stream) {
+  int rc = d4gs_pose_encode_impl(R, r_stride, T, t_stride, enc, stream);
+  if (rc) return rc;
+  MlpPtrs p;
+  for (int l = 0; l < 9; l++) p.w[l] = w[l], p.b[l] = b[l];
+  {
+    ProfScope ps("k_move_mlp_fwd", stream);
+    k_move_mlp_fwd<<<1, 256, 0, stream>>>(enc, p, acts, delta, delta + 6);
+  }
+  rc = d4gs_check_launch("k_move_mlp_fwd");
+  if (rc) return rc;
+  return d4gs_camera_path_fwd_impl(delta, delta + 6, S, time_params, index, t, moving, RTs, jac, times, dtimes, deltaT,
+                                   stream);
+}
+
+int d4gs_move_model_bwd_impl(const float *jac, const float *dtimes, const float *deltaT, const float *acts,
+                             const float *const *w, const float *const *b, const float *v_RTs, const float *v_times,
+                             const float *v_deltaT, int32_t S, int32_t index, int32_t n_time_params, float *v_delta,
+                             float *const *v_w, float *const *v_b, float *v_time_params, hipStream_t stream) {
+  int rc = d4gs_camera_path_bwd_impl(jac, dtimes, deltaT, v_RTs, v_times, v_deltaT, S, index, n_time_params, v_delta,
+                                     v_delta + 6, v_time_params, stream);
+  if (rc) return rc;
+  MlpPtrs p;
+  MlpGradPtrs g;
+  for (int l = 0; l < 9; l++) p.w[l] = w[l], p.b[l] = b[l], g.w[l] = v_w[l], g.b[l] = v_b[l];
+  ProfScope ps("k_move_mlp_bwd", stream);
+  k_move_mlp_bwd<<<1, 256, 0, stream>>>(acts, p, v_delta, v_delta + 6, g);
+  return d4gs_check_launch("k_move_mlp_bwd");
 }

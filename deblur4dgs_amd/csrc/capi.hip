@@ -26,6 +26,13 @@ int d4gs_camera_path_fwd_impl(const float *, const float *, int32_t, const float
 int d4gs_camera_path_bwd_impl(const float *, const float *, const float *, const float *, const float *,
                               const float *, int32_t, int32_t, int32_t, float *, float *, float *, hipStream_t);
 
+int d4gs_move_model_fwd_impl(const float *, int32_t, const float *, int32_t, const float *const *, const float *const *,
+                             int32_t, const float *, int32_t, float, int32_t, float *, float *, float *, float *, float *,
+                             float *, float *, float *, hipStream_t);
+int d4gs_move_model_bwd_impl(const float *, const float *, const float *, const float *, const float *const *,
+                             const float *const *, const float *, const float *, const float *, int32_t, int32_t, int32_t,
+                             float *, float *const *, float *const *, float *, hipStream_t);
+
 static thread_local char g_err[512] = "";
 
 // ---- per-kernel event profiler -------------------------------------------------------------------------
@@ -253,6 +260,42 @@ int d4gs_camera_path_bwd(const float *jac, const float *dtimes, const float *del
   }
   return d4gs_camera_path_bwd_impl(jac, dtimes, deltaT, v_RTs, v_times, v_deltaT, S, index, n_time_params, v_delta0,
                                    v_delta1, v_time_params, (hipStream_t)stream);
+}
+
+int d4gs_move_model_fwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const D4gsMoveModelParams *p,
+                        int32_t S, int32_t index, float t, int32_t stage_first, const D4gsMoveModelOut *o, void *stream) {
+  if (!R || !T || !p || !o || r_stride < 3 || t_stride < 1 || S <= 0 || S > 4096) {
+    d4gs_set_error("move_model_fwd: bad arguments (S=%d r_stride=%d t_stride=%d)", S, r_stride, t_stride);
+    return D4GS_EINVAL;
+  }
+  for (int l = 0; l < 9; l++)
+    if (!p->w[l] || !p->b[l]) {
+      d4gs_set_error("move_model_fwd: layer %d has a NULL weight or bias", l);
+      return D4GS_EINVAL;
+    }
+  if (!o->enc || !o->acts || !o->delta || !o->RTs || !o->times || !o->dtimes || !o->deltaT) {
+    d4gs_set_error("move_model_fwd: NULL output buffer");
+    return D4GS_EINVAL;
+  }
+  const int moving = !stage_first && p->time_params && index > 0 && index < p->n_time_params - 1;
+  return d4gs_move_model_fwd_impl(R, r_stride, T, t_stride, p->w, p->b, S, p->time_params, index, t, moving, o->enc,
+                                  o->acts, o->delta, o->RTs, o->jac, o->times, o->dtimes, o->deltaT, (hipStream_t)stream);
+}
+
+int d4gs_move_model_bwd(const D4gsMoveModelParams *p, const D4gsMoveModelOut *o, const float *v_RTs, const float *v_times,
+                        const float *v_deltaT, int32_t S, int32_t index, const D4gsMoveModelGrads *g, void *stream) {
+  if (!p || !o || !g || S <= 0 || p->n_time_params < 0 || p->n_time_params > 52 || !o->jac || !o->acts || !g->v_delta ||
+      (p->n_time_params > 0 && !g->v_time_params)) {
+    d4gs_set_error("move_model_bwd: bad arguments");
+    return D4GS_EINVAL;
+  }
+  for (int l = 0; l < 9; l++)
+    if (!g->v_w[l] || !g->v_b[l]) {
+      d4gs_set_error("move_model_bwd: layer %d has a NULL gradient buffer", l);
+      return D4GS_EINVAL;
+    }
+  return d4gs_move_model_bwd_impl(o->jac, o->dtimes, o->deltaT, o->acts, p->w, p->b, v_RTs, v_times, v_deltaT, S, index,
+                                  p->n_time_params, g->v_delta, g->v_w, g->v_b, g->v_time_params, (hipStream_t)stream);
 }
 
 }  // extern "C"

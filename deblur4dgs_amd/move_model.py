@@ -180,6 +180,65 @@ def pose_encode(R, T):
     return enc
 
 
+MLP_ACTS = P_input_ch + 7 * 64
+
+
+class MoveModelFn(torch.autograd.Function):
+    """The whole module for one pose in one C call each way (d4gs_move_model_fwd / _bwd): pose encoding, the 9-layer
+    MLP and the camera path.  params = (time_params, w0, b0, .., w8, b8) in the layer order of include/d4gs.h."""
+
+    @staticmethod
+    def forward(ctx, R, T, S, index, t, stage_first, time_params, *wb):
+        from . import _lib as L
+
+        dev = R.device
+        if R.stride(1) != 1:
+            R = R.contiguous()
+        T = T.reshape(3, -1)[:, 0]
+        ws = [x.detach().contiguous() for x in wb[0::2]]
+        bs = [x.detach().contiguous() for x in wb[1::2]]
+        tp = time_params.detach().contiguous()
+        buf = torch.empty(P_input_ch + MLP_ACTS + 12 + S * 12 + S * 144 + 2 * S + 2, device=dev, dtype=torch.float32)
+        enc, acts, delta, RTs, jac, times, dtimes, dT = buf.split([P_input_ch, MLP_ACTS, 12, S * 12, S * 144, S, S, 2])
+        pp = L.MoveModelParams()
+        for l in range(9):
+            pp.w[l], pp.b[l] = ws[l].data_ptr(), bs[l].data_ptr()
+        pp.time_params, pp.n_time_params = tp.data_ptr(), tp.numel()
+        out = L.fill(L.MoveModelOut(), enc=enc, acts=acts, delta=delta, RTs=RTs, jac=jac, times=times, dtimes=dtimes,
+                     deltaT=dT)
+        L.check(L.lib().d4gs_move_model_fwd(_p(R), R.stride(0), _p(T), T.stride(0), C.byref(pp), S, index, float(t),
+                                            int(stage_first), C.byref(out), _stream(R)), "move_model_fwd")
+        ctx.keep = (buf, ws, bs, tp)  # non-differentiable buffers (plain attributes: no version checks needed)
+        ctx.meta = (S, index, time_params.shape, [x.shape for x in wb])
+        return RTs.view(S, 3, 4), times.view(1, S), dT[:1].view(1, 1)
+
+    @staticmethod
+    def backward(ctx, v_RTs, v_times, v_dT):
+        from . import _lib as L
+
+        buf, ws, bs, tp = ctx.keep
+        S, index, tp_shape, shapes = ctx.meta
+        enc, acts, delta, RTs, jac, times, dtimes, dT = buf.split([P_input_ch, MLP_ACTS, 12, S * 12, S * 144, S, S, 2])
+        cont = lambda v: None if v is None else v.contiguous().float()
+        v_RTs, v_times, v_dT = cont(v_RTs), cont(v_times), cont(v_dT)
+        sizes = [tp.numel(), 12] + [x.numel() for pair in zip(ws, bs) for x in pair]
+        gbuf = torch.empty(sum(sizes), device=buf.device, dtype=torch.float32)
+        parts = gbuf.split(sizes)
+        pp = L.MoveModelParams()
+        gg = L.MoveModelGrads()
+        for l in range(9):
+            pp.w[l], pp.b[l] = ws[l].data_ptr(), bs[l].data_ptr()
+            gg.v_w[l], gg.v_b[l] = parts[2 + 2 * l].data_ptr(), parts[3 + 2 * l].data_ptr()
+        pp.time_params, pp.n_time_params = tp.data_ptr(), tp.numel()
+        gg.v_time_params, gg.v_delta = parts[0].data_ptr(), parts[1].data_ptr()
+        out = L.fill(L.MoveModelOut(), enc=enc, acts=acts, delta=delta, RTs=RTs, jac=jac, times=times, dtimes=dtimes,
+                     deltaT=dT)
+        L.check(L.lib().d4gs_move_model_bwd(C.byref(pp), C.byref(out), _p(v_RTs), _p(v_times), _p(v_dT), S, index,
+                                            C.byref(gg), _stream(buf)), "move_model_bwd")
+        grads = [parts[2 + k].view(shapes[k]) for k in range(18)]
+        return (None, None, None, None, None, None, parts[0].view(tp_shape), *grads)
+
+
 class CameraPathFn(torch.autograd.Function):
     """(delta0 [1,6], delta1 [1,6], time_params [1,P]) -> RTs [S,3,4], times [1,S], deltaT [1,1]."""
 
@@ -244,6 +303,12 @@ class MoveModel(nn.Module):
     def postprocessPose(self, RT):
         return se3_to_SE3(RT)
 
+    def _layer_params(self):
+        """(w, b) of the 9 linear layers in the order of include/d4gs.h."""
+        lin = [self.RT_main[0], self.RT_main[2], self.RT_main[4], self.RT_main[6], self.RT_main[8], self.RT_head0[0],
+               self.RT_head0[2], self.RT_head1[0], self.RT_head1[2]]
+        return [p for l in lin for p in (l.weight, l.bias)]
+
     def _fused(self, R, T):
         return R.is_cuda and not (R.requires_grad or T.requires_grad) and R.dtype == T.dtype == torch.float32
 
@@ -275,11 +340,9 @@ class MoveModel(nn.Module):
     def forward_start_end_mid(self, info, num_cameras=10, mode="uniform", stage="second"):
         R, T, time = info["R"], info["T"], info["timestep"]
         if self._fused(R, T) and num_cameras > 1:
-            d0, d1 = self._heads(R, T)
-            index = int(time)
-            moving = stage != "first" and 0 < index < self.time_params.shape[-1] - 1
             assert mode == "uniform"  # the only mode the reference calls (scene_model.py:254,272)
-            return CameraPathFn.apply(d0, d1, self.time_params, num_cameras, index, float(time), moving)
+            return MoveModelFn.apply(R, T, num_cameras, int(time), float(time), stage == "first", self.time_params,
+                                     *self._layer_params())
         RT_start, RT_end, time_start, time_end = self.forward(R, T, time, stage=stage)
         RTs = self._interpolate(se3_Exp(RT_start), se3_Exp(RT_end), num_cameras=num_cameras, mode=mode)  # [1,S,7]
         RTs = self.postprocessPose(SE3_Log(RTs)).squeeze(0)  # [S,3,4]

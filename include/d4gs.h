@@ -223,6 +223,38 @@ int d4gs_camera_path_bwd(const float *jac, const float *dtimes, const float *del
 int d4gs_pose_encode(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc /* [66] */,
                      void *stream);
 
+/* The whole MoveModel (move_model.py:66-166) for one pose, one call each way: d4gs_pose_encode -> the 9-layer MLP
+ * (66 -> 64 x4 LeakyReLU(0.01) -> 64, heads 64 -> 64 -> 6; ~30 GEMV launches per render in eager PyTorch) ->
+ * d4gs_camera_path_fwd.  Layer order in w[] / b[]: RT_main.0, .2, .4, .6, .8, RT_head0.0, .2, RT_head1.0, .2;
+ * weights are [out,in] row-major as nn.Linear stores them. */
+typedef struct {
+  const float *w[9];
+  const float *b[9];
+  const float *time_params; /* [n_time_params] or NULL */
+  int32_t n_time_params;
+} D4gsMoveModelParams;
+typedef struct {
+  float *enc;    /* [66]  scratch */
+  float *acts;   /* [514] saved layer inputs (backward) */
+  float *delta;  /* [12]  the two head outputs */
+  float *RTs;    /* [S,3,4] */
+  float *jac;    /* [S,12,12] */
+  float *times;  /* [S] */
+  float *dtimes; /* [S] */
+  float *deltaT; /* [2] */
+} D4gsMoveModelOut;
+typedef struct {
+  float *v_w[9];
+  float *v_b[9];
+  float *v_time_params; /* [n_time_params] */
+  float *v_delta;       /* [12] scratch */
+} D4gsMoveModelGrads;
+int d4gs_move_model_fwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const D4gsMoveModelParams *p,
+                        int32_t S, int32_t index, float t, int32_t stage_first, const D4gsMoveModelOut *out, void *stream);
+int d4gs_move_model_bwd(const D4gsMoveModelParams *p, const D4gsMoveModelOut *out, const float *v_RTs,
+                        const float *v_times, const float *v_deltaT, int32_t S, int32_t index,
+                        const D4gsMoveModelGrads *grads, void *stream);
+
 /* a9 exposure blend (scene_model.py:386-397): out = mean_S; policy[c] 1 -> max over {raw_0..raw_{S-2}, mean},
  * 2 -> min over the same set (the reference's in-place quirk); acc = mean_S alphas. */
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] [C] */,
