@@ -1,11 +1,20 @@
-"""Densification statistics: fused replacement for the accumulation loop of
-`Trainer._prepare_control_step` (reference flow3d/trainer.py:953-990).
+"""Adaptive Gaussian control.
+
+* statistics: fused replacement for the accumulation loop of `Trainer._prepare_control_step`
+  (reference flow3d/trainer.py:953-990) - one HIP kernel per render;
+* control steps: `densify_step`, `cull_step`, `reset_opacity_step` mirror `Trainer._densify_control_step`,
+  `_cull_control_step`, `_reset_opacity_control_step` (trainer.py:992-1166) and the optimizer-state surgery of
+  `dup_in_optim` / `remove_from_optim` / `reset_in_optim` (trainer.py:1199-1252).  They run every 100 steps on a few
+  MB of parameters (host logic over torch index ops, as upstream); what matters for the hot path is that N changes
+  between steps - every workspace of the renderer is sized per call, so nothing has to be re-queried by hand.
 
 `running_stats` is the reference's dict of per-Gaussian tensors (`xys_grad_norm_acc` f32, `vis_count` i64,
 `max_radii` f32); they are updated in place by one HIP kernel per render instead of ~10 torch launches per
 sub-sample.
 """
 from __future__ import annotations
+
+from dataclasses import dataclass
 
 import torch
 
@@ -35,3 +44,153 @@ def accumulate_from_model(running_stats: dict, model, batch_size: int, update_ma
     xys = torch.cat([x.grad for x in model._current_xys], 0)
     rad = torch.cat(list(model._current_radii), 0)
     accumulate_control_stats(running_stats, xys, rad, model._current_img_wh, batch_size, update_max_radii)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class ControlCfg:
+    """The reference's adaptive-control knobs with their defaults (flow3d/configs.py:51-67)."""
+    warmup_steps: int = 200
+    control_every: int = 100
+    reset_opacity_every_n_controls: int = 30
+    stop_control_by_screen_steps: int = 4000
+    stop_control_steps: int = 4000
+    densify_xys_grad_threshold: float = 0.0002
+    densify_scale_threshold: float = 0.01
+    densify_screen_threshold: float = 0.05
+    stop_densify_steps: int = 15000
+    cull_opacity_threshold: float = 0.1
+    cull_scale_threshold: float = 0.5
+    cull_screen_threshold: float = 0.15
+
+    @property
+    def reset_opacity_every(self) -> int:
+        return self.control_every * self.reset_opacity_every_n_controls
+
+
+def new_running_stats(n: int, device) -> dict:
+    return {"xys_grad_norm_acc": torch.zeros(n, device=device), "vis_count": torch.zeros(n, dtype=torch.int64, device=device),
+            "max_radii": torch.zeros(n, device=device)}
+
+
+def _swap_param(optimizer, i: int, p_new, edit_state):
+    """Re-key optimizer.state from the old Parameter of group i to `p_new`, editing every per-row tensor."""
+    old = optimizer.param_groups[i]["params"][0]
+    state = optimizer.state.get(old, {})
+    if len(state) == 0:  # the optimizer has not stepped yet: nothing to carry over (and, as upstream, the group
+        return False     # keeps pointing at the old Parameter - callers re-create optimizers in that case)
+    for key in list(state):
+        if key == "step":
+            continue
+        state[key] = edit_state(state[key])
+    del optimizer.state[old]
+    optimizer.state[p_new] = state
+    optimizer.param_groups[i]["params"] = [p_new]
+    return True
+
+
+def dup_in_optim(optimizer, new_params: list, should_split: torch.Tensor, num_new: int):
+    """Adam moments after `densify_params`: rows of the kept Gaussians, then zeros for every new row."""
+    assert len(optimizer.param_groups) == len(new_params)
+    for i, p in enumerate(new_params):
+        if not _swap_param(optimizer, i, p, lambda m: torch.cat([m[~should_split], m.new_zeros(num_new, *m.shape[1:])], 0)):
+            return
+
+
+def remove_from_optim(optimizer, new_params: list, should_cull: torch.Tensor):
+    assert len(optimizer.param_groups) == len(new_params)
+    for i, p in enumerate(new_params):
+        if not _swap_param(optimizer, i, p, lambda m: m[~should_cull]):
+            return
+
+
+def reset_in_optim(optimizer, new_params: list):
+    """Upstream zeroes every entry of the state here, `step` included."""
+    assert len(optimizer.param_groups) == len(new_params)
+    for i, p in enumerate(new_params):
+        old = optimizer.param_groups[i]["params"][0]
+        state = optimizer.state.get(old, {})
+        if len(state) == 0:
+            return
+        for key in list(state):
+            state[key] = torch.zeros_like(state[key])
+        del optimizer.state[old]
+        optimizer.state[p] = state
+        optimizer.param_groups[i]["params"] = [p]
+
+
+def _parts(model, only_fg: bool):
+    return [("fg", model.fg)] + ([("bg", model.bg)] if (model.bg is not None and not only_fg) else [])
+
+
+@torch.no_grad()
+def densify_step(model, running_stats: dict, optimizers: dict, cfg: ControlCfg, global_step: int, only_fg: bool = False):
+    """trainer.py:992-1079.  `optimizers` maps "fg.params.means" etc. to single-parameter optimizers (may be empty).
+    Returns (n_split, n_dup)."""
+    vis = running_stats["vis_count"]
+    assert (vis > 0).any()
+    grad_avg = running_stats["xys_grad_norm_acc"] / vis.clamp_min(1)
+    grad_high = grad_avg > cfg.densify_xys_grad_threshold
+    scale_big = model.get_scales_all().amax(-1) > cfg.densify_scale_threshold
+    if global_step < cfg.stop_control_by_screen_steps:
+        radius_big = running_stats["max_radii"] > cfg.densify_screen_threshold
+    else:
+        radius_big = torch.zeros_like(grad_high)
+    split = grad_high & (scale_big | radius_big)
+    dup = grad_high & ~scale_big
+    nfg = model.num_fg_gaussians
+    masks = {"fg": (split[:nfg], dup[:nfg]), "bg": (split[nfg:], dup[nfg:])}
+    for name, part in _parts(model, only_fg):
+        sp, du = masks[name]
+        n_new = 2 * int(sp.sum()) + int(du.sum())
+        for pname, p_new in part.densify_params(sp, du).items():
+            opt = optimizers.get(f"{name}.params.{pname}")
+            if opt is not None:
+                dup_in_optim(opt, [p_new], sp, n_new)
+    for k, v in running_stats.items():  # same row order as densify_params: kept, duplicated, split twice
+        chunks = []
+        for name, lo, hi in (("fg", 0, nfg), ("bg", nfg, v.shape[0])):
+            part_v = v[lo:hi]
+            if name == "bg" and (only_fg or model.bg is None):
+                chunks.append(part_v)
+                continue
+            sp, du = masks[name]
+            chunks += [part_v[~sp], part_v[du], part_v[sp].repeat(2)]
+        running_stats[k] = torch.cat(chunks, 0)
+    return int(split.sum()), int(dup.sum())
+
+
+@torch.no_grad()
+def cull_step(model, running_stats: dict, optimizers: dict, cfg: ControlCfg, global_step: int, only_fg: bool = False):
+    """trainer.py:1081-1141.  Returns the number of culled Gaussians."""
+    opac = model.get_opacities_all()
+    cull = opac < cfg.cull_opacity_threshold
+    nfg = model.num_fg_gaussians
+    if global_step > cfg.reset_opacity_every:
+        thr = torch.full((opac.shape[0],), cfg.cull_scale_threshold, device=opac.device)
+        thr[nfg:] *= model.bg_scene_scale
+        cull = cull | (model.get_scales_all().amax(-1) > thr)
+        if global_step < cfg.stop_control_by_screen_steps:
+            cull = cull | (running_stats["max_radii"] > cfg.cull_screen_threshold)
+    masks = {"fg": cull[:nfg], "bg": cull[nfg:]}
+    for name, part in _parts(model, only_fg):
+        for pname, p_new in part.cull_params(masks[name]).items():
+            opt = optimizers.get(f"{name}.params.{pname}")
+            if opt is not None:
+                remove_from_optim(opt, [p_new], masks[name])
+    if only_fg:
+        cull = torch.cat([masks["fg"], torch.zeros_like(masks["bg"])], 0)
+    for k, v in running_stats.items():
+        running_stats[k] = v[~cull]
+    return int(cull.sum())
+
+
+@torch.no_grad()
+def reset_opacity_step(model, optimizers: dict, cfg: ControlCfg, only_fg: bool = False):
+    """trainer.py:1143-1166: every opacity logit := logit(0.8 * cull threshold), Adam state zeroed."""
+    new_val = torch.logit(torch.tensor(0.8 * cfg.cull_opacity_threshold))
+    for name, part in _parts(model, only_fg):
+        for pname, p in part.reset_opacities(new_val).items():
+            opt = optimizers.get(f"{name}.params.{pname}")
+            if opt is not None:
+                reset_in_optim(opt, [p])

@@ -13,6 +13,8 @@ after the in-place mean write, so `exposure_imgs[-1]` is the blended frame (:386
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -71,6 +73,32 @@ class GaussianParams(nn.Module):
         return F.softmax(self.params["motion_coefs"], dim=-1)
 
 
+    # ---- adaptive control (flow3d/params.py:86-118): the model side of densify / cull / reset ----------------
+    def densify_params(self, should_split, should_dup):
+        """Row surgery on every parameter: kept rows (not split), then the duplicated rows, then every split row twice
+        (the two halves of a split get scales / 1.6, i.e. log-scale - log 1.6).  Returns {name: new Parameter}."""
+        out = {}
+        for name in list(self.params.keys()):
+            x = self.params[name]
+            halves = x[should_split].repeat(2, *([1] * (x.ndim - 1)))
+            if name == "scales":
+                halves = halves - math.log(1.6)
+            out[name] = nn.Parameter(torch.cat([x[~should_split], x[should_dup], halves], 0))
+            self.params[name] = out[name]
+        return out
+
+    def cull_params(self, should_cull):
+        out = {}
+        for name in list(self.params.keys()):
+            out[name] = nn.Parameter(self.params[name][~should_cull])
+            self.params[name] = out[name]
+        return out
+
+    def reset_opacities(self, new_val):
+        self.params["opacities"].data.fill_(float(new_val))
+        return {"opacities": self.params["opacities"]}
+
+
 class MotionBases(nn.Module):
     """flow3d/params.py:121-180: `rots [K,T,6]`, `transls [K,T,3]`."""
 
@@ -118,6 +146,19 @@ class SceneModel(nn.Module):
     num_fg_gaussians = property(lambda self: self.fg.num_gaussians)
     num_motion_bases = property(lambda self: self.motion_bases.num_bases)
     has_bg = property(lambda self: self.bg is not None)
+
+    def _all(self, getter: str) -> torch.Tensor:  # scene_model.py:122-143: fg rows first, then bg
+        parts = [getattr(self.fg, getter)()] + ([getattr(self.bg, getter)()] if self.bg is not None else [])
+        return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+
+    def get_colors_all(self) -> torch.Tensor:
+        return self._all("get_colors")
+
+    def get_scales_all(self) -> torch.Tensor:
+        return self._all("get_scales")
+
+    def get_opacities_all(self) -> torch.Tensor:
+        return self._all("get_opacities")
 
     @staticmethod
     def init_from_state_dict(state_dict, prefix=""):

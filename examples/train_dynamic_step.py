@@ -3,8 +3,8 @@
 
 Mirrors the SHAPE of the reference's `Trainer.train_step` (flow3d/trainer.py:203-274) - three render groups per step
 (static `bg_only` blurry frame, dynamic full blurry frame with mask / track / depth channels, static `mid` frame),
-an L1 photometric loss, one Adam optimizer per parameter tensor, and the densification statistics of
-`_prepare_control_step` - without the reference's data pipeline, PWC-Net / SSIM losses or control steps
+an L1 photometric loss, one Adam optimizer per parameter tensor, the densification statistics of
+`_prepare_control_step` and (with --control-every) the densify / cull control steps - without the reference's data pipeline, PWC-Net / SSIM losses or control steps
 (out of scope).  It exists to show the seam in a real autograd + optimizer loop:
 
     python examples/train_dynamic_step.py --steps 20
@@ -20,7 +20,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from deblur4dgs_amd.control import accumulate_from_model  # noqa: E402
+from deblur4dgs_amd.control import ControlCfg, accumulate_from_model, cull_step, densify_step  # noqa: E402
 from deblur4dgs_amd.scene_model import GaussianParams, MotionBases, SceneModel  # noqa: E402
 from deblur4dgs_amd.synth import make_scene  # noqa: E402
 
@@ -35,7 +35,7 @@ def build(n_fg=40_000, n_bg=100_000, K=20, W=512, H=288, dev="cuda:0", seed=0):
     return model.to(dev), sc
 
 
-def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, **kw):
+def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, **kw):
     model, sc = build(W=W, H=H, dev=dev, **kw)
     w2c, K = sc["viewmat"][None].to(dev), sc["K"][None].to(dev)
     # targets: renders of a perturbed copy of the scene (so the loss has something to fit)
@@ -43,12 +43,14 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, **kw):
         tgt_model, _ = build(W=W, H=H, dev=dev, seed=1, **kw)
         tgt_dyn = tgt_model.render(3, w2c, K, (W, H), mode="blury")["img"]
         tgt_sta = tgt_model.render(3, w2c, K, (W, H), bg_only=True, mode="blury")["img"]
-    opts = [torch.optim.Adam([p], lr=lr, fused=p.is_cuda) for p, lr in
-            [(p, 1.6e-4) for p in (model.fg.params["means"], model.bg.params["means"])] +
-            [(p, 1e-2) for n, p in model.named_parameters() if "colors" in n or "opacities" in n] +
-            [(p, 5e-3) for n, p in model.named_parameters() if "scales" in n or "quats" in n or "motion_coefs" in n] +
-            [(p, 1.6e-4) for p in model.motion_bases.parameters()] +
-            [(p, 5e-4) for p in model.move_model.parameters()]]
+    adam = lambda p, lr: torch.optim.Adam([p], lr=lr, fused=p.is_cuda)
+    lrs = {"means": 1.6e-4, "colors": 1e-2, "opacities": 1e-2, "scales": 5e-3, "quats": 5e-3, "motion_coefs": 5e-3}
+    # one Adam per tensor, keyed like the reference's Trainer.optimizers (trainer.py:1168-1196): the control steps
+    # re-key them when rows are added / removed
+    optimizers = {f"{part}.params.{n}": adam(p, lrs[n]) for part in ("fg", "bg") for n, p in getattr(model, part).params.items()}
+    others = [adam(p, 1.6e-4) for p in model.motion_bases.parameters()] + [adam(p, 5e-4) for p in model.move_model.parameters()]
+    opts = lambda: list(optimizers.values()) + others
+    cfg = ControlCfg()
     N = model.num_gaussians
     stats = {"xys_grad_norm_acc": torch.zeros(N, device=dev), "vis_count": torch.zeros(N, dtype=torch.int64, device=dev),
              "max_radii": torch.zeros(N, device=dev)}
@@ -60,7 +62,7 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, **kw):
         if it == warm:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        for o in opts:
+        for o in opts():
             o.zero_grad(set_to_none=True)
         out1 = model.render(3, w2c, K, (W, H), bg_only=True, return_depth=True, return_mask=True, mode="blury")
         out2 = model.render(3, w2c, K, (W, H), target_ts=target_ts, target_w2cs=target_w2cs, return_depth=True,
@@ -70,18 +72,25 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, **kw):
         loss = (out1["img"] - tgt_sta).abs().mean() + (out2["img"] - tgt_dyn).abs().mean() + \
             0.1 * (out3["img"] - tgt_sta).abs().mean() + 1e-3 * out2["tracks_3d"].square().mean()
         loss.backward()
-        for o in opts:
+        for o in opts():
             o.step()
         model._current_xys, model._current_radii, model._current_img_wh = xys2, radii2, wh2
         accumulate_from_model(stats, model, batch_size=1)
         losses.append(loss.detach())  # no host sync inside the loop
+        if control_every and it > 0 and it % control_every == 0:  # adaptive control: N changes between steps
+            n_split, n_dup = densify_step(model, stats, optimizers, cfg, global_step=it)
+            n_cull = cull_step(model, stats, optimizers, cfg, global_step=it)
+            for v in stats.values():
+                v.zero_()
+            if verbose:
+                print(f"step {it:3d}  control: split {n_split}, dup {n_dup}, cull {n_cull} -> {model.num_gaussians} Gaussians")
         if verbose and (it % 10 == 0 or it == steps - 1):
             print(f"step {it:3d}  loss {float(losses[-1]):.5f}")
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (steps - warm)
     losses = [float(l) for l in losses]
     if verbose:
-        print(f"{1e3 * dt:.2f} ms / step  (3 render groups: 11 + 11 + 1 sub-samples, {N} Gaussians, fwd + bwd + Adam)")
+        print(f"{1e3 * dt:.2f} ms / step  (3 render groups: 11 + 11 + 1 sub-samples, {model.num_gaussians} Gaussians, fwd + bwd + Adam)")
         print(f"visible-instance count accumulated: {int(stats['vis_count'].sum())}")
     return losses, stats, dt
 
@@ -89,5 +98,6 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, **kw):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--control-every", type=int, default=0, help="densify + cull every N steps (0: never)")
     a = ap.parse_args()
-    train(a.steps)
+    train(a.steps, control_every=a.control_every)

@@ -11,6 +11,7 @@ CPU-runnable parts of the path are covered:
   F3  cont_6d_to_rmat (incl. near-parallel inputs)        flow3d/transforms.py:41-53
   F4  SE3_to_se3 / se3_to_SE3                             flow3d/models/utils/spline_utils.py:177-215
   F5  MoveModel.forward with a fixed non-zero state_dict  flow3d/models/move_model.py:112-135
+  F6  GaussianParams.densify_params / cull_params / reset_opacities   flow3d/params.py:86-118
 
 `roma`, `pypose`, `jaxtyping` are absent from the image; they are imported by these modules but never
 called on the code paths exercised here, so empty stub modules stand in for the import statements.
@@ -153,6 +154,36 @@ def main():
                 case += 1
     f5["n_cases"] = np.int64(case)
     np.savez_compressed(os.path.join(OUT, "f5_move_model.npz"), **f5)
+
+    # ---- F6 ------------------------------------------------------------------------------------
+    f6 = {}
+    gen = torch.Generator().manual_seed(77)
+    names = ("means", "quats", "scales", "colors", "opacities", "motion_coefs")
+    for c, (G, K) in enumerate(((40, 4), (7, 0), (64, 6))):
+        raw = dict(means=torch.randn(G, 3, generator=gen), quats=torch.randn(G, 4, generator=gen),
+                   scales=torch.randn(G, 3, generator=gen), colors=torch.randn(G, 3, generator=gen),
+                   opacities=torch.randn(G, generator=gen))
+        if K > 0:
+            raw["motion_coefs"] = torch.randn(G, K, generator=gen)
+        split = torch.rand(G, generator=gen) < 0.3
+        dup = (torch.rand(G, generator=gen) < 0.3) & ~split
+        cull = torch.rand(G, generator=gen) < 0.4
+        f6[f"c{c}_split"], f6[f"c{c}_dup"], f6[f"c{c}_cull"] = split.numpy(), dup.numpy(), cull.numpy()
+        for k, v in raw.items():
+            f6[f"c{c}_in_{k}"] = v.numpy()
+        mk = lambda: GaussianParams(raw["means"].clone(), raw["quats"].clone(), raw["scales"].clone(), raw["colors"].clone(),
+                                    raw["opacities"].clone(), raw["motion_coefs"].clone() if K > 0 else None)
+        gp = mk()
+        for k, v in gp.densify_params(split, dup).items():
+            f6[f"c{c}_densify_{k}"] = v.detach().numpy()
+        gp = mk()
+        for k, v in gp.cull_params(cull).items():
+            f6[f"c{c}_cull_{k}"] = v.detach().numpy()
+        gp = mk()
+        for k, v in gp.reset_opacities(torch.logit(torch.tensor(0.08))).items():
+            f6[f"c{c}_reset_{k}"] = v.detach().numpy()
+    f6["n_cases"] = np.int64(3)
+    np.savez_compressed(os.path.join(OUT, "f6_control_params.npz"), **f6)
     print("wrote fixtures to", OUT)
 
 

@@ -155,3 +155,20 @@ def test_training_loop_example_reduces_the_loss():
     assert all(l == l and l < 1e3 for l in losses)
     assert losses[-1] < 0.9 * losses[0], losses
     assert int(stats["vis_count"].sum()) > 0 and float(stats["xys_grad_norm_acc"].sum()) > 0
+
+
+def test_training_with_control_steps_changes_n_and_keeps_training():
+    """SURVEY 8f-1 end to end: statistics kernel -> densify / cull decisions -> parameter + Adam-state surgery; the
+    renderer is called with a different N right after (every workspace is sized per call)."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_dynamic_step.py")
+    spec = importlib.util.spec_from_file_location("train_dynamic_step_ctl", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n0 = 8000
+    losses, stats, _ = mod.train(steps=16, W=128, H=96, n_fg=3000, n_bg=5000, K=6, verbose=False, control_every=5)
+    assert all(l == l and l < 1e3 for l in losses)
+    assert stats["vis_count"].shape[0] != n0            # Gaussians were added / removed (controls at steps 5, 10, 15)
+    assert losses[14] < losses[11] and losses[9] < losses[6]   # and the optimizers keep working on the new rows
