@@ -72,7 +72,8 @@ EXPORTS = (
     "d4gs_version", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
     "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_control_stats", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
-    "d4gs_pose_encode", "d4gs_move_model_fwd", "d4gs_move_model_bwd", "d4gs_profile_enable", "d4gs_profile_collect",
+    "d4gs_pose_encode", "d4gs_move_model_fwd", "d4gs_move_model_bwd",
+    "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_profile_enable", "d4gs_profile_collect",
 )
 
 _lib = None
@@ -112,6 +113,12 @@ def lib() -> C.CDLL:
                                           C.c_int32, P(MoveModelOut), vp]
         L.d4gs_move_model_bwd.argtypes = [P(MoveModelParams), P(MoveModelOut), vp, vp, vp, C.c_int32, C.c_int32,
                                           P(MoveModelGrads), vp]
+        L.d4gs_photometric_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        L.d4gs_photometric_blocks.restype = C.c_int64
+        L.d4gs_photometric_fwd.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, vp, vp,
+                                           vp, vp]
+        L.d4gs_photometric_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                           C.c_float, vp, vp]
         L.d4gs_blend_fwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp]
         L.d4gs_blend_bwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp, vp, vp]
         if L.d4gs_version() != 100:

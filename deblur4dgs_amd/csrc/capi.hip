@@ -33,6 +33,11 @@ int d4gs_move_model_bwd_impl(const float *, const float *, const float *, const 
                              const float *const *, const float *, const float *, const float *, int32_t, int32_t, int32_t,
                              float *, float *const *, float *const *, float *, hipStream_t);
 
+int d4gs_photometric_fwd_impl(const float *, const float *, const float *, int32_t, int32_t, int32_t, float, float, float *,
+                              float *, float *, hipStream_t);
+int d4gs_photometric_bwd_impl(const float *, const float *, const float *, const float *, const float *, int32_t, int32_t,
+                              int32_t, float, float, float *, hipStream_t);
+
 static thread_local char g_err[512] = "";
 
 // ---- per-kernel event profiler -------------------------------------------------------------------------
@@ -296,6 +301,29 @@ int d4gs_move_model_bwd(const D4gsMoveModelParams *p, const D4gsMoveModelOut *o,
     }
   return d4gs_move_model_bwd_impl(o->jac, o->dtimes, o->deltaT, o->acts, p->w, p->b, v_RTs, v_times, v_deltaT, S, index,
                                   p->n_time_params, g->v_delta, g->v_w, g->v_b, g->v_time_params, (hipStream_t)stream);
+}
+
+int d4gs_photometric_fwd(const float *pred, const float *gt, const float *mask, int32_t B, int32_t H, int32_t W, int32_t C,
+                         float w_l1, float w_ssim, float *maps, float *partials, float *loss, void *stream) {
+  if (C != 3 || B <= 0 || H < 11 || W < 11) {
+    d4gs_set_error("photometric: needs C == 3 and H, W >= 11 (B=%d H=%d W=%d C=%d)", B, H, W, C);
+    return D4GS_EINVAL;
+  }
+  if (!pred || !gt || !maps || !partials || !loss) {
+    d4gs_set_error("photometric_fwd: NULL buffer");
+    return D4GS_EINVAL;
+  }
+  return d4gs_photometric_fwd_impl(pred, gt, mask, B, H, W, w_l1, w_ssim, maps, partials, loss, (hipStream_t)stream);
+}
+
+int d4gs_photometric_bwd(const float *pred, const float *gt, const float *mask, const float *maps, const float *v_loss,
+                         int32_t B, int32_t H, int32_t W, int32_t C, float w_l1, float w_ssim, float *v_pred,
+                         void *stream) {
+  if (C != 3 || B <= 0 || H < 11 || W < 11 || !pred || !gt || !maps || !v_loss || !v_pred) {
+    d4gs_set_error("photometric_bwd: bad arguments");
+    return D4GS_EINVAL;
+  }
+  return d4gs_photometric_bwd_impl(pred, gt, mask, maps, v_loss, B, H, W, w_l1, w_ssim, v_pred, (hipStream_t)stream);
 }
 
 }  // extern "C"

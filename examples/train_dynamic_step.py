@@ -3,9 +3,9 @@
 
 Mirrors the SHAPE of the reference's `Trainer.train_step` (flow3d/trainer.py:203-274) - three render groups per step
 (static `bg_only` blurry frame, dynamic full blurry frame with mask / track / depth channels, static `mid` frame),
-an L1 photometric loss, one Adam optimizer per parameter tensor, the densification statistics of
-`_prepare_control_step` and (with --control-every) the densify / cull control steps - without the reference's data pipeline, PWC-Net / SSIM losses or control steps
-(out of scope).  It exists to show the seam in a real autograd + optimizer loop:
+the reference's photometric loss (0.8 L1 + 0.2 (1 - SSIM), fused), one Adam optimizer per parameter tensor, the
+densification statistics of `_prepare_control_step` and (with --control-every) the densify / cull control steps -
+without the reference's data pipeline or its PWC-Net / depth / track losses (out of scope).  It exists to show the seam in a real autograd + optimizer loop:
 
     python examples/train_dynamic_step.py --steps 20
 """
@@ -21,6 +21,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from deblur4dgs_amd.control import ControlCfg, accumulate_from_model, cull_step, densify_step  # noqa: E402
+from deblur4dgs_amd.losses import photometric_loss  # noqa: E402
 from deblur4dgs_amd.scene_model import GaussianParams, MotionBases, SceneModel  # noqa: E402
 from deblur4dgs_amd.synth import make_scene  # noqa: E402
 
@@ -69,8 +70,9 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, *
                             return_mask=True, mode="blury")  # 17 channels
         xys2, radii2, wh2 = model._current_xys, model._current_radii, model._current_img_wh
         out3 = model.render(3, w2c, K, (W, H), bg_only=True, return_depth=True, mode="mid")
-        loss = (out1["img"] - tgt_sta).abs().mean() + (out2["img"] - tgt_dyn).abs().mean() + \
-            0.1 * (out3["img"] - tgt_sta).abs().mean() + 1e-3 * out2["tracks_3d"].square().mean()
+        # the reference's photometric term, 0.8 L1 + 0.2 (1 - SSIM) (trainer.py:388-392,575-586), fused
+        loss = photometric_loss(out1["img"], tgt_sta) + photometric_loss(out2["img"], tgt_dyn) + \
+            0.1 * photometric_loss(out3["img"], tgt_sta) + 1e-3 * out2["tracks_3d"].square().mean()
         loss.backward()
         for o in opts():
             o.step()

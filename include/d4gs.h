@@ -255,6 +255,19 @@ int d4gs_move_model_bwd(const D4gsMoveModelParams *p, const D4gsMoveModelOut *ou
                         const float *v_times, const float *v_deltaT, int32_t S, int32_t index,
                         const D4gsMoveModelGrads *grads, void *stream);
 
+/* the photometric loss term, fused (flow3d/trainer.py:388-392,575-586):
+ *   loss = w_l1 * mean|pred*m - gt*m| + w_ssim * (1 - SSIM(pred*m, gt*m)),
+ * SSIM = pytorch_msssim.SSIM(data_range=1, size_average=True, channel=3) [11-tap sigma-1.5 window, no padding].
+ * pred, gt [B,H,W,3] channel-last; mask [B,H,W] or NULL.  Forward: loss[3] = {loss, l1, ssim} (device), plus what the
+ * backward needs: maps [B,H-10,W-10,3,3], partials [d4gs_photometric_blocks(B,H,W), 2] scratch.  Backward:
+ * v_pred [B,H,W,3] = dL/dpred * v_loss[0] (v_loss is a device scalar). */
+int64_t d4gs_photometric_blocks(int32_t B, int32_t H, int32_t W);
+int d4gs_photometric_fwd(const float *pred, const float *gt, const float *mask, int32_t B, int32_t H, int32_t W, int32_t C,
+                         float w_l1, float w_ssim, float *maps, float *partials, float *loss, void *stream);
+int d4gs_photometric_bwd(const float *pred, const float *gt, const float *mask, const float *maps, const float *v_loss,
+                         int32_t B, int32_t H, int32_t W, int32_t C, float w_l1, float w_ssim, float *v_pred,
+                         void *stream);
+
 /* a9 exposure blend (scene_model.py:386-397): out = mean_S; policy[c] 1 -> max over {raw_0..raw_{S-2}, mean},
  * 2 -> min over the same set (the reference's in-place quirk); acc = mean_S alphas. */
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] [C] */,
