@@ -17,16 +17,16 @@ struct EmitArgs {
   D4gsDims d;
   const float *depths;
   const int32_t *tile_rects;
-  const int32_t *tile_ranks;
   const int32_t *tiles_touched;
   const int32_t *isect_offsets;
-  int32_t *tile_cursor;  // tile_counts: [0,T) counts of the rank-carrying splats, [T,2T) cursors of the wide ones
+  int32_t *tile_cursor;  // tile_counts: [0,T) splats per tile, [T,2T) slot cursors (zero on entry)
   const int32_t *tile_offsets;
   uint64_t *keys;
   int32_t *gid_of_emit;
   int tw, th;
   const int64_t *n_dev;  // device {total, longest list}: the launch is a no-op when they exceed what the caller sized
   int64_t cap, max_hint;
+  int use_lds;
 };
 
 // D4gsIsect.n_isect is a CAPACITY: the host may size the lists from a guess and look at the real count afterwards.
@@ -34,48 +34,67 @@ __device__ __forceinline__ bool over_capacity(const int64_t *n_dev, int64_t cap,
   return n_dev && (n_dev[0] > cap || (max_hint > 0 && n_dev[1] > max_hint));
 }
 
-// Block b takes the same 4096 instances of sub-sample b % S as k_count_tiles' block b (1024 lanes x 4): the ranks it
-// hands out per tile are consecutive inside such a chunk, so the 8-byte key stores of one block fall into short
-// contiguous runs of every tile list and merge in that XCD's L2 instead of reaching memory as partial lines.
+// Slot assignment without per-intersection global atomics.  Block b takes 4096 instances of sub-sample b % S
+// (1024 lanes x 4, the chunks of k_count_tiles):
+//   1. histogram of the chunk's tile touches in LDS;
+//   2. ONE returning global atomic per non-empty tile reserves the chunk's run inside that tile's (unsorted) list;
+//      the bin becomes the absolute first slot of the run;
+//   3. every (instance, tile) takes the next slot of its bin with an LDS atomic and writes its key there.
+// Which slot a key lands in is irrelevant (k_tile_sort orders the list by depth, then emission index), so nothing
+// has to be carried from the counting pass, splats of any footprint take the same path, and the 8-byte key stores
+// of a block fall into short contiguous runs.  Tile grids too big for the LDS histogram use global cursors.
 constexpr int EMIT_THREADS = 1024, EMIT_PER_THREAD = 4;
 __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
+  extern __shared__ int bins[];  // [tiles]
   if (over_capacity(a.n_dev, a.cap, a.max_hint)) return;
+  const int tiles = a.tw * a.th, tid = threadIdx.x;
   const int s = blockIdx.x % a.d.S, chunk = blockIdx.x / a.d.S;
-  const int tbase = s * a.tw * a.th;
-  const int n_tiles_all = a.d.S * a.tw * a.th;
-#pragma unroll 1
+  const int tbase = s * tiles, n_tiles_all = a.d.S * tiles;
+  const bool lds = a.use_lds;
+  if (lds) {
+    for (int z = tid; z < tiles; z += EMIT_THREADS) bins[z] = 0;
+    __syncthreads();
+  }
+  int cnt[EMIT_PER_THREAD], rx[EMIT_PER_THREAD], ry[EMIT_PER_THREAD];
+#pragma unroll
   for (int q = 0; q < EMIT_PER_THREAD; q++) {
-    const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + threadIdx.x;
-    if (g >= a.d.N) continue;
+    const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
+    cnt[q] = 0;
+    if (g < a.d.N) {
+      const int64_t i = (int64_t)s * a.d.N + g;
+      cnt[q] = a.tiles_touched[i];
+      if (cnt[q] > 0) {
+        const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
+        rx[q] = rc.x, ry[q] = rc.y;
+        if (lds) {
+          const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+          for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++) atomicAdd(&bins[ty * a.tw + tx], 1);
+        }
+      }
+    }
+  }
+  if (lds) {
+    __syncthreads();
+    for (int z = tid; z < tiles; z += EMIT_THREADS) {
+      const int c = bins[z];
+      if (c > 0) bins[z] = a.tile_offsets[tbase + z] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + z, c);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < EMIT_PER_THREAD; q++) {
+    if (cnt[q] == 0) continue;
+    const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
     const int64_t i = (int64_t)s * a.d.N + g;
-    const int cnt = a.tiles_touched[i];
-    if (cnt == 0) continue;
-    const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
-    const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+    const int x0 = rx[q] & 0xffff, x1 = rx[q] >> 16, y0 = ry[q] & 0xffff, y1 = ry[q] >> 16;
     const uint64_t hi = (uint64_t)__float_as_uint(a.depths[i]) << 32;
     uint32_t e = (uint32_t)a.isect_offsets[i];
-    if (cnt <= D4GS_RANK_SLOTS) {  // ranks came out of the counting pass: no atomics here
-      const int4 *rp = reinterpret_cast<const int4 *>(a.tile_ranks + i * D4GS_RANK_SLOTS);
-      const int4 rk = rp[0];
-      int4 rk2 = make_int4(0, 0, 0, 0);
-      if (cnt > 4) rk2 = rp[1];
-      const int r[8] = {rk.x, rk.y, rk.z, rk.w, rk2.x, rk2.y, rk2.z, rk2.w};
-      const int w = x1 - x0;
-#pragma unroll
-      for (int k = 0; k < D4GS_RANK_SLOTS; k++)
-        if (k < cnt) {
-          const int t = tbase + (y0 + k / w) * a.tw + x0 + k % w;
-          const int slot = a.tile_offsets[t] + r[k];
-          a.keys[slot] = hi | (e + k);
-          a.gid_of_emit[e + k] = g;
-        }
-      continue;
-    }
     for (int ty = y0; ty < y1; ty++)
       for (int tx = x0; tx < x1; tx++) {
-        const int t = tbase + ty * a.tw + tx;
-        // wide splats sit behind the rank-carrying ones in the (unsorted) tile segment
-        const int slot = a.tile_offsets[t] + a.tile_cursor[t] + atomicSub(a.tile_cursor + n_tiles_all + t, 1) - 1;
+        const int t = ty * a.tw + tx;
+        const int slot = lds ? atomicAdd(&bins[t], 1)
+                             : a.tile_offsets[tbase + t] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + t, 1);
         a.keys[slot] = hi | e;
         a.gid_of_emit[e] = g;
         e++;
@@ -248,7 +267,6 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.d = *dims;
   e.depths = proj->depths;
   e.tile_rects = proj->tile_rects;
-  e.tile_ranks = proj->tile_ranks;
   e.tiles_touched = proj->tiles_touched;
   e.isect_offsets = proj->isect_offsets;
   e.tile_cursor = proj->tile_counts;
@@ -259,7 +277,10 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   e.n_dev = proj->n_isect, e.cap = isect->n_isect, e.max_hint = isect->max_tile_count;
   const int per_block = EMIT_THREADS * EMIT_PER_THREAD;
-  D4GS_LAUNCH("k_emit", k_emit, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS), 0, stream, e);
+  const size_t bins_bytes = sizeof(int) * (size_t)e.tw * e.th;
+  e.use_lds = bins_bytes <= 64 * 1024;
+  D4GS_LAUNCH("k_emit", k_emit, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS),
+              e.use_lds ? bins_bytes : 0, stream, e);
   int rc = d4gs_check_launch("k_emit");
   if (rc) return rc;
   const int n_tiles = dims->S * e.tw * e.th;

@@ -8,7 +8,7 @@
 #define D4GS_WAVE 64
 #define D4GS_MAX_K 32         // motion bases held in LDS per block
 #define D4GS_PROJ_BLOCK 256
-#define D4GS_RANK_SLOTS 8      // splats touching <= 8 tiles get their tile-list ranks from the counting atomics
+
 
 // host-side error plumbing (capi.cpp)
 void d4gs_set_error(const char *fmt, ...);

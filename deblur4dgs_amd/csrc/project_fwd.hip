@@ -166,24 +166,9 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       cnt = (x1 - x0) * (y1 - y0);
       const int n_tiles_all = S * a.tw * a.th;
       int *tc = a.out.tile_counts + (size_t)s * a.tw * a.th;
-      if (a.count_apart) {
-        // counted / ranked by k_count_tiles
-      } else if (cnt <= D4GS_RANK_SLOTS) {
-        // common case: the RETURNING atomic is both the count and this splat's rank inside the tile list, so the
-        // emit pass needs no atomics at all for it (up to 8 independent atomics in flight, one wait)
-        const int w = x1 - x0;
-        int r[D4GS_RANK_SLOTS];
-#pragma unroll
-        for (int k = 0; k < D4GS_RANK_SLOTS; k++) {
-          r[k] = 0;
-          if (k < cnt) r[k] = atomicAdd(tc + (y0 + k / w) * a.tw + x0 + k % w, 1);
-        }
-        int4 *rp = reinterpret_cast<int4 *>(a.out.tile_ranks + i * D4GS_RANK_SLOTS);
-        rp[0] = make_int4(r[0], r[1], r[2], r[3]);
-        if (cnt > 4) rp[1] = make_int4(r[4], r[5], r[6], r[7]);
-      } else {  // wide splats: counted apart (second half of tile_counts), ranked by k_emit
+      if (!a.count_apart) {  // tile grids too big for the LDS histogram: plain global atomics
         for (int ty = y0; ty < y1; ty++)
-          for (int tx = x0; tx < x1; tx++) atomicAdd(tc + n_tiles_all + ty * a.tw + tx, 1);
+          for (int tx = x0; tx < x1; tx++) atomicAdd(tc + ty * a.tw + tx, 1);
       }
     }
     a.out.radii[i] = p.radius;
@@ -201,72 +186,36 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Tile counting + ranking, LDS-aggregated.  Device-scope atomics execute memory-side on this part (~27 G/s on spread
+// Tile counting, LDS-aggregated.  Device-scope atomics execute memory-side on this part (~27 G/s on spread
 // addresses): one per (splat, tile) cost k_project_fwd 0.15 of its 0.23 ms.  Here a 1024-lane block takes 4096
-// instances of ONE sub-sample, counts them into an LDS histogram of that sub-sample's tiles (the returning LDS atomic
-// is the splat's rank inside the block), then adds each non-empty bin to the global counter with ONE returning atomic
-// whose result is the block's base rank in that tile list: ~13x fewer global atomics, ranks stay in registers.
-// Splats touching more than D4GS_RANK_SLOTS tiles are only counted (second half of tile_counts), as before.
+// instances of ONE sub-sample, counts their tiles into an LDS histogram of that sub-sample's tile grid and adds
+// every non-empty bin to the global counter with one atomic: ~13x fewer global atomics.  (k_emit later repeats the
+// same histogram to hand out the slots, see binning.hip.)
 // ---------------------------------------------------------------------------------------------------
 constexpr int COUNT_THREADS = 1024, COUNT_PER_THREAD = 4;
 __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__restrict__ tile_rects,
                                                               const int *__restrict__ tiles_touched, int N, int S, int tw,
-                                                              int th, int *__restrict__ tile_counts,
-                                                              int *__restrict__ tile_ranks) {
-  extern __shared__ int hist[];  // [2][tiles]: splats with <= RANK_SLOTS tiles | wide splats
+                                                              int th, int *__restrict__ tile_counts) {
+  extern __shared__ int hist[];  // [tiles]
   const int tiles = tw * th, tid = threadIdx.x;
   const int s = blockIdx.x % S, chunk = blockIdx.x / S;  // neighbouring blocks work on different sub-samples' counters
-  for (int z = tid; z < 2 * tiles; z += COUNT_THREADS) hist[z] = 0;
+  for (int z = tid; z < tiles; z += COUNT_THREADS) hist[z] = 0;
   __syncthreads();
-  int r[COUNT_PER_THREAD][D4GS_RANK_SLOTS], cnt[COUNT_PER_THREAD], first[COUNT_PER_THREAD], wd[COUNT_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < COUNT_PER_THREAD; q++) {
     const int g = (chunk * COUNT_PER_THREAD + q) * COUNT_THREADS + tid;
-    cnt[q] = 0;
-    if (g < N) {
-      const size_t i = (size_t)s * N + g;
-      cnt[q] = tiles_touched[i];
-      if (cnt[q] > 0) {
-        const int2 rc = *reinterpret_cast<const int2 *>(tile_rects + i * 2);
-        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-        wd[q] = x1 - x0, first[q] = y0 * tw + x0;
-        if (cnt[q] <= D4GS_RANK_SLOTS) {
-#pragma unroll
-          for (int k = 0; k < D4GS_RANK_SLOTS; k++) {
-            r[q][k] = 0;
-            if (k < cnt[q]) r[q][k] = atomicAdd(&hist[first[q] + (k / wd[q]) * tw + k % wd[q]], 1);
-          }
-        } else {
-          for (int ty = y0; ty < y1; ty++)
-            for (int tx = x0; tx < x1; tx++) atomicAdd(&hist[tiles + ty * tw + tx], 1);
-        }
-      }
-    }
+    if (g >= N) continue;
+    const size_t i = (size_t)s * N + g;
+    if (tiles_touched[i] == 0) continue;
+    const int2 rc = *reinterpret_cast<const int2 *>(tile_rects + i * 2);
+    const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+    for (int ty = y0; ty < y1; ty++)
+      for (int tx = x0; tx < x1; tx++) atomicAdd(&hist[ty * tw + tx], 1);
   }
   __syncthreads();
-  const size_t n_tiles_all = (size_t)S * tiles;
-  for (int z = tid; z < 2 * tiles; z += COUNT_THREADS) {
+  for (int z = tid; z < tiles; z += COUNT_THREADS) {
     const int c = hist[z];
-    if (c > 0) {
-      if (z < tiles)
-        hist[z] = atomicAdd(tile_counts + (size_t)s * tiles + z, c);  // base rank of this block in the tile's list
-      else
-        atomicAdd(tile_counts + n_tiles_all + (size_t)s * tiles + (z - tiles), c);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < COUNT_PER_THREAD; q++) {
-    if (cnt[q] > 0 && cnt[q] <= D4GS_RANK_SLOTS) {
-      const int g = (chunk * COUNT_PER_THREAD + q) * COUNT_THREADS + tid;
-      const size_t i = (size_t)s * N + g;
-#pragma unroll
-      for (int k = 0; k < D4GS_RANK_SLOTS; k++)
-        if (k < cnt[q]) r[q][k] += hist[first[q] + (k / wd[q]) * tw + k % wd[q]];
-      int4 *rp = reinterpret_cast<int4 *>(tile_ranks + i * D4GS_RANK_SLOTS);
-      rp[0] = make_int4(r[q][0], r[q][1], r[q][2], r[q][3]);
-      if (cnt[q] > 4) rp[1] = make_int4(r[q][4], r[q][5], r[q][6], r[q][7]);
-    }
+    if (c > 0) atomicAdd(tile_counts + (size_t)s * tiles + z, c);
   }
 }
 
@@ -410,7 +359,7 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
     return D4GS_EINVAL;
   }
   const int blocks = (dims->N + D4GS_PROJ_BLOCK - 1) / D4GS_PROJ_BLOCK;
-  const size_t hist_bytes = sizeof(int) * 2 * (size_t)a.tw * a.th;
+  const size_t hist_bytes = sizeof(int) * (size_t)a.tw * a.th;
   static const bool force_in_kernel = getenv("D4GS_COUNT_IN_PROJECT") != nullptr;  // test hook for the fallback
   a.count_apart = hist_bytes <= 64 * 1024 && dims->N > 0 && !force_in_kernel;  // bigger tile grids: in-kernel atomics
   D4GS_LAUNCH("k_project_fwd", k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
@@ -421,7 +370,7 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
     const int cblocks = ((dims->N + per_block - 1) / per_block) * dims->S;
     D4GS_LAUNCH("k_count_tiles", k_count_tiles, dim3(cblocks), dim3(COUNT_THREADS), hist_bytes, stream,
                 (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th,
-                out->tile_counts, out->tile_ranks);
+                out->tile_counts);
     rc = d4gs_check_launch("k_count_tiles");
     if (rc) return rc;
   }

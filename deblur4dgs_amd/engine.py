@@ -126,7 +126,7 @@ class ProjectFn(torch.autograd.Function):
             radii=torch.empty(S, N, **i32), opac_act=torch.empty(N, **f32), ctab=torch.empty(N, cfg.DP, **f32),
             geom=torch.empty(S * N, L.GEOM_STRIDE, **f32), tile_rects=torch.empty(S * N, 2, **i32),
             tiles_touched=torch.empty(S * N, **i32),
-            isect_offsets=torch.empty(S * N, **i32), tile_ranks=torch.empty(S * N, 8, **i32),
+            isect_offsets=torch.empty(S * N, **i32), tile_ranks=None,
             tile_counts=torch.empty(2 * S * tw * th, **i32),
             tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(2, dtype=torch.int64, device=dev),
             scan_ws=torch.empty(lib.d4gs_scan_ws_elems(S * N), **i32),

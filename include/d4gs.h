@@ -93,9 +93,10 @@ typedef struct D4gsProjOut {
   int32_t *tile_rects;     /* [S*N,2] packed tile rectangle: x0 | x1<<16 , y0 | y1<<16 (min incl., max excl.) */
   int32_t *tiles_touched;  /* [S*N] */
   int32_t *isect_offsets;  /* [S*N] exclusive scan of tiles_touched */
-  int32_t *tile_ranks;     /* [S*N,8] rank of the instance inside each of its (<= 8) tile lists */
-  int32_t *tile_counts;    /* [2*S*tiles]: [0,T) splats per tile that carry ranks, [T,2T) wide splats per tile
-                              (consumed as cursors by d4gs_bin_sort); T = S*tiles */
+  int32_t *tile_ranks;     /* unused since the slots are handed out inside d4gs_bin_sort (kept for layout; may be NULL) */
+  int32_t *tile_counts;    /* [2*S*tiles]: [0,T) splats per tile, [T,2T) per-tile slot cursors - zeroed by
+                              d4gs_project_fwd and consumed by d4gs_bin_sort, which therefore runs once per projection
+                              (a launch refused by the capacity check does not touch them); T = S*tiles */
   int32_t *tile_offsets;   /* [S*tiles+1] exclusive scan of tile_counts */
   int64_t *n_isect;        /* [2] {total intersections, longest tile list} - read back by the host to size the next
                               stage and to pick the sort size classes */
