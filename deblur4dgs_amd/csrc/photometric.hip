@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int PW = 11, PR = 5, PT = 16, PH = PT + PW - 1;  // window, radius, tile, tile + halo (26)
+constexpr int PW = 11, PT = 16, PH = PT + PW - 1;  // window, tile, tile + halo (26)
 constexpr int PC = 3;                                      // channels (the reference's SSIM is built for 3)
 __constant__ float c_win[PW] = {0.00102838f, 0.00759876f, 0.03600077f, 0.10936069f, 0.21300554f, 0.26601172f,
                                 0.21300554f, 0.10936069f, 0.03600077f, 0.00759876f, 0.00102838f};

@@ -164,7 +164,6 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       if (d.flags & D4GS_EXACT_CULL) tight_rect(m2x, m2y, opac, p.a, p.c, x0, y0, x1, y1);
       rect = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       cnt = (x1 - x0) * (y1 - y0);
-      const int n_tiles_all = S * a.tw * a.th;
       int *tc = a.out.tile_counts + (size_t)s * a.tw * a.th;
       if (!a.count_apart) {  // tile grids too big for the LDS histogram: plain global atomics
         for (int ty = y0; ty < y1; ty++)

@@ -723,7 +723,7 @@ struct GatherArgs {
 
 // The rows of the 64 instances a wave owns (same sub-sample, consecutive Gaussians) form ONE contiguous span of
 // isect_grad: the wave streams it into LDS with coalesced loads and every lane then sums its own rows from there, in
-// the same k order as a direct read (bit-identical).  Spans longer than the LDS budget (wide splats) are read directly.
+// the same k order as a direct read (bit-identical).  Spans longer than the LDS budget (wide splats) take several chunks.
 constexpr int GATHER_THREADS = 128, GATHER_ROWS = 192;  // rows of LDS per wave
 template <int D, bool DEPTH>
 __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
@@ -747,27 +747,24 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
     int endl = off + cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) endl = max(endl, __shfl_xor(endl, o));
-    const int rows = endl - base;
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.f;
-    if (rows <= GATHER_ROWS) {
-      const float *src = a.isect_grad + (size_t)base * R;
-      const int nf = rows * R;
+    // the span is streamed in chunks of GATHER_ROWS rows; a lane's rows [off, off + cnt) are contiguous, so it adds
+    // the part of them that lies in the current chunk - always in ascending k, whatever the chunking
+    for (int cb = base; cb < endl; cb += GATHER_ROWS) {
+      const int ce = min(cb + GATHER_ROWS, endl);
+      const float *src = a.isect_grad + (size_t)cb * R;
+      const int nf = (ce - cb) * R;
       for (int f = lane; f < nf; f += 64) mine[f] = src[f];
       __builtin_amdgcn_wave_barrier();
-      const float *row = mine + (off - base) * R;
-      for (int k = 0; k < cnt; k++, row += R) {
+      const int k0 = max(off, cb), k1 = min(off + cnt, ce);
+      const float *row = mine + (k0 - cb) * R;
+      for (int k = k0; k < k1; k++, row += R) {
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] += row[r];
       }
       __builtin_amdgcn_wave_barrier();
-    } else {
-      const float *row = a.isect_grad + (size_t)off * R;
-      for (int k = 0; k < cnt; k++, row += R) {
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] += row[r];
-      }
     }
     if (in) {
       *reinterpret_cast<float2 *>(a.v_means2d + i * 2) = make_float2(acc[0], acc[1]);
