@@ -173,9 +173,11 @@ __device__ __forceinline__ void chunk_block(uint64_t (&v)[NV], int lane) {  // t
 // distance is < 64 run inside one wave on 64-key chunks held in registers - four chunks per wave at a time, so the
 // exchange latencies overlap - and the k-blocks 2..64 run back to back without touching LDS; only the steps with
 // distance >= 64 go through LDS with a barrier each.
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t *key, int P) {
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *key, int P, int n) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int nchunks = P >> 6;
+  // keys [n, P) are UINT64_MAX padding: in this all-ascending network a pair whose upper partner is padding never
+  // swaps, so chunks made of padding only and cross-chunk pairs reaching into it are skipped (work ~ n, not P)
+  const int nchunks = (n + 63) >> 6;
   for (int c0 = wv; c0 < nchunks; c0 += 4 * nw) {
     uint64_t v[4];
 #pragma unroll
@@ -197,8 +199,10 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t *key, int P) {
         const int blk = t / j, off = t - blk * j;
         const int i = blk * 2 * j + off;
         const int l = (j == (k >> 1)) ? (blk * 2 * j + (2 * j - 1 - off)) : (i + j);
-        const uint64_t a = key[i], b = key[l];
-        if (a > b) key[i] = b, key[l] = a;
+        if (l < n) {
+          const uint64_t a = key[i], b = key[l];
+          if (a > b) key[i] = b, key[l] = a;
+        }
       }
       __syncthreads();
     }
@@ -239,7 +243,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(const SortArgs a) {
     while (P < n) P <<= 1;
     for (int p = threadIdx.x; p < P; p += blockDim.x) skeys[p] = p < n ? gk[p] : ~0ull;
     __syncthreads();
-    bitonic_sort_lds(skeys, P);
+    bitonic_sort_lds(skeys, P, n);
     for (int p = threadIdx.x; p < n; p += blockDim.x) {
       const uint32_t e = (uint32_t)skeys[p];
       a.sorted_emit[base + p] = (int32_t)e;
