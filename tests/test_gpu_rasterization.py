@@ -379,3 +379,39 @@ def test_seeded_random_sweep_forward_and_backward(i, mode, D, N, W, H, scale_mul
         assert torch.isfinite(got).all()
         # a handful of Gaussians: one alpha >= 1/255 decision taken differently in fp32 moves a whole row by ~0.5 %
         assert frac_bad(got, ref, 2e-3) < 1e-2 or rel_err(got, ref) < 1e-2, (name, rel_err(got, ref))
+
+
+@pytest.mark.parametrize("D", [3, 16])
+def test_backward_variants_agree(D):
+    """Variant B (default; for D >= 16 with the colour rows on the matrix pipe), variant A (one wave per tile) and
+    variant C (all reductions on MFMA) differ only in the order of their pixel sums."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tests.util import static_inputs
+from deblur4dgs_amd.rasterization import rasterization
+D = %d
+inp = static_inputs(6000, 200, 120, seed=77, dtype=torch.float32, D=D, scale_mul=3.0)
+t = {k: v.cuda().requires_grad_(k != "K") for k, v in inp.items()}
+rc, ra, info = rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"][None], t["K"][None], 200, 120,
+                             render_mode="RGB+ED")
+g = torch.Generator().manual_seed(3)
+w = torch.randn(rc.shape, generator=g).cuda()
+((rc * w).sum() + (ra * ra).sum()).backward()
+torch.cuda.synchronize()
+torch.save([t[k].grad.cpu() for k in ("means", "quats", "scales", "opac", "colors")], sys.argv[1])
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), D)
+    outs = []
+    for env_extra, name in (({}, "/tmp/d4gs_bwd_b.pt"), ({"D4GS_BWD_WAVE_PER_TILE": "1"}, "/tmp/d4gs_bwd_a.pt"),
+                            ({"D4GS_BWD_MFMA": "1"}, "/tmp/d4gs_bwd_c.pt")):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("D4GS_BWD_")}
+        env.update(env_extra)
+        subprocess.check_call([sys.executable, "-c", code, name], env=env)
+        outs.append(torch.load(name))
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert rel_err(y, x) < 2e-5, rel_err(y, x)
