@@ -205,15 +205,20 @@ struct ProfScope {
   ~ProfScope();
 };
 
-// sigma * log2(e) of a splat at a pixel offset (dx, dy); g1 = conic pre-scaled by log2(e).  Used verbatim by both
-// forward variants AND the backward's alpha recomputation: explicit FMAs with contraction off, so every kernel (and
-// every unrolled copy of a loop body) rounds identically - the forward/backward valid-pixel decisions and the
-// "variant A == variant B", "exact cull on == off" bitwise guarantees depend on it.
+// sigma * log2(e) of a splat at a pixel offset (dx, dy) in 5 operations.  g1 = (a/2, b, c/2) * log2(e) as staged by
+// the raster kernels (stage_conic).  Used verbatim by every forward variant AND the backward's alpha recomputation:
+// explicit FMAs with contraction off, so every kernel (and every unrolled copy of a loop body) rounds identically -
+// the forward/backward valid-pixel decisions and the "variants bit-identical", "exact cull on == off" guarantees
+// depend on it.
 __device__ __forceinline__ float splat_sigma2(const float4 g1, float dx, float dy) {
 #pragma clang fp contract(off)
-  const float t = g1.x * dx, u = g1.z * dy;
-  const float q = __builtin_fmaf(t, dx, u * dy);
-  return __builtin_fmaf(0.5f, q, (g1.y * dx) * dy);
+  const float inner = __builtin_fmaf(g1.x, dx, g1.y * dy);  // a/2 dx + b dy
+  return __builtin_fmaf(dx, inner, (g1.z * dy) * dy);       // dx (a/2 dx + b dy) + c/2 dy^2
+}
+// LDS record of a conic for splat_sigma2; w is free for the caller
+__device__ __forceinline__ float4 stage_conic(float a, float b, float c, float w) {
+  constexpr float LOG2E_ = 1.4426950408889634f;
+  return make_float4(a * (0.5f * LOG2E_), b * LOG2E_, c * (0.5f * LOG2E_), w);
 }
 
 // ---- fused DPP adds ------------------------------------------------------------------------------------------
@@ -269,9 +274,10 @@ __device__ __forceinline__ void rowsum_all(float (&z)[NR]) {
   if constexpr (r == 2) rowsum2(z[NR - 2], z[NR - 1]);
   if constexpr (r == 1) rowsum1(z[NR - 1]);
 }
-// Sum v[0..R) over the wave and store the R totals to dst[0..R) (LDS); dst[R] must be a writable pad slot.
+// Sum v[0..R) over the wave and store the R totals to arr[at .. at + R) (LDS); arr[at + R] must be a writable pad
+// slot.  `arr` is the __shared__ array itself and `at` an int offset so that the address math stays 32-bit.
 template <int R>
-__device__ __forceinline__ void wave_sum_store(float (&v)[R], float *dst, int lane) {
+__device__ __forceinline__ void wave_sum_store(float (&v)[R], float *arr, int at, int lane) {
   constexpr int n4 = R / 4, rem = R % 4, n2 = rem / 2, n1 = rem % 2, NR = n4 + n2 + n1;
   float z[NR];
 #pragma unroll
@@ -286,10 +292,14 @@ __device__ __forceinline__ void wave_sum_store(float (&v)[R], float *dst, int la
     const int r = lane >> 4;
     const int o4 = ((r & 1) << 1) | (r >> 1);  // rows hold (v0, v2, v1, v3)
 #pragma unroll
-    for (int g = 0; g < n4; g++) dst[4 * g + o4] = z[g];
-    if constexpr (n2) dst[(r & 1) ? 4 * n4 + (r >> 1) : R] = z[n4];
-    if constexpr (n1) dst[r == 3 ? R - 1 : R] = z[NR - 1];
+    for (int g = 0; g < n4; g++) arr[at + 4 * g + o4] = z[g];
+    if constexpr (n2) arr[at + ((r & 1) ? 4 * n4 + (r >> 1) : R)] = z[n4];
+    if constexpr (n1) arr[at + (r == 3 ? R - 1 : R)] = z[NR - 1];
   }
+}
+template <int R>
+__device__ __forceinline__ void wave_sum_store(float (&v)[R], float *dst, int lane) {
+  wave_sum_store(v, dst, 0, lane);
 }
 
 #define D4GS_LAUNCH(name, kernel, grid, block, lds, stream, ...)            \

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
   hi = min(wave_max_i(hi), end - 1);
   const size_t inst_base = (size_t)s * a.N;
 
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  constexpr float LN2 = 0.6931471805599453f;
   for (int bh = hi; bh >= start; bh -= 64) {
     __syncthreads();
     const int idx = bh - lane;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
       const float4 q0 = gp[0], q1 = gp[1];
       sg0[lane] = q0;
       // conic pre-scaled by log2(e) (exp2 argument) and 1/opacity for the opacity adjoint
-      sg1[lane] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, __builtin_amdgcn_rcpf(q0.z));
+      sg1[lane] = stage_conic(q1.x, q1.y, q1.z, __builtin_amdgcn_rcpf(q0.z));
       const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
 #pragma unroll
       for (int v = 0; v < DV; v++) scol[lane * DV + v] = cp[v];
@@ -191,8 +191,8 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
         row[2] += vsx * dx[p];              // 2 * dL/da
         row[3] += vsx * dy[p];              // dL/db
         row[4] += vsy * dy[p];              // 2 * dL/dc
-        row[0] += g1.x * vsx + g1.y * vsy;  // log2e * dL/dx
-        row[1] += g1.y * vsx + g1.z * vsy;  // log2e * dL/dy
+        row[0] += 2.f * g1.x * vsx + g1.y * vsy;  // log2e * dL/dx   (g1 = (a/2, b, c/2) log2e)
+        row[1] += g1.y * vsx + 2.f * g1.z * vsy;  // log2e * dL/dy
         row[5] -= vs;                       // opacity * dL/dopacity
       }
       row[0] *= LN2, row[1] *= LN2, row[2] *= 0.5f, row[4] *= 0.5f, row[5] *= g1.w;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   constexpr int CB = MC ? RV + 1 : 6;         // slab column of channel 0 (VALU rows, their pad slot, then colours)
   constexpr int FS = 17;                      // fac tile [64 px][16 hits], row stride (bank-conflict padding)
   static_assert(!MC || CB + MC <= RP, "slab row too short");
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  constexpr float LN2 = 0.6931471805599453f;
   __shared__ float sfac[MC ? 4 * 64 * FS : 1];
   __shared__ int shit[MC ? 4 * 16 : 1];
   __shared__ float4 sg0[NB];
@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   const int hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
   const size_t inst_base = (size_t)s * a.N;
   float *myslab = sgrad + wv * NB * RP;
+  const int wvs = __builtin_amdgcn_readfirstlane(wv);  // wave-uniform: keeps the slab row address scalar
   // A fragments (lane l holds A[row = l & 15][k = l >> 4]): channel l & 15 at quadrant pixel 4 kk + (l >> 4)
   float afrag[MC ? 16 : 1];
   float *myfac = sfac + (MC ? wv * 64 * FS : 0);
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
         const float4 q0 = gp[0], q1 = gp[1];
         sg0[tid] = q0;
-        sg1[tid] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, __builtin_amdgcn_rcpf(q0.z));
+        sg1[tid] = stage_conic(q1.x, q1.y, q1.z, __builtin_amdgcn_rcpf(q0.z));
         const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
         const float det = q1.x * q1.z - q1.y * q1.y;
         const float idet = 1.f / det;
@@ -419,7 +420,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         row[3] = vsx * dy;
         row[4] = vsy * dy;
         row[5] = vs;
-        wave_sum_store(row, myslab + j * RP, lane);
+        wave_sum_store(row, sgrad, (wvs * NB + j) * RP, lane);
         if constexpr (MC > 0) {
           if (++nh == 16) {
             flush(16);
@@ -442,8 +443,8 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
       }
       const float4 g1 = sg1[tid];  // conic * log2(e), 1 / opacity
       float *dst = a.isect_grad + (size_t)emit * R;
-      dst[0] = (g1.x * sum[0] + g1.y * sum[1]) * LN2;  // dL/dx = a Sum(vs dx) + b Sum(vs dy)
-      dst[1] = (g1.y * sum[0] + g1.z * sum[1]) * LN2;
+      dst[0] = (2.f * g1.x * sum[0] + g1.y * sum[1]) * LN2;  // dL/dx = a Sum(vs dx) + b Sum(vs dy); g1 = (a/2, b, c/2) log2e
+      dst[1] = (g1.y * sum[0] + 2.f * g1.z * sum[1]) * LN2;
       dst[2] = 0.5f * sum[2];
       dst[3] = sum[3];
       dst[4] = 0.5f * sum[4];
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
   constexpr int HF = 8;               // valid splats per MFMA flush (half of the 16 columns of a 16x16x4 tile: LDS budget)
   constexpr int TS = 66;              // transposed-tile row stride (floats): conflict-free B-fragment reads
   constexpr int CB = (NCH + 15) / 16; // 16-row colour blocks
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  constexpr float LN2 = 0.6931471805599453f;
   __shared__ float4 sg0[NB];
   __shared__ float4 sg1[NB];
   __shared__ float4 sbox[NB];
@@ -616,8 +617,8 @@ __global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
       const float Dxy = mx * (my * S0 - Sy) - my * Sx + Sxy;
       const float Dyy = my * (my * S0 - 2.f * Sy) + Syy;
       float *dst = myslab + j * RP;
-      dst[0] = (g1.x * Dx + g1.y * Dy) * LN2;
-      dst[1] = (g1.y * Dx + g1.z * Dy) * LN2;
+      dst[0] = (2.f * g1.x * Dx + g1.y * Dy) * LN2;
+      dst[1] = (g1.y * Dx + 2.f * g1.z * Dy) * LN2;
       dst[2] = 0.5f * Dxx;
       dst[3] = Dxy;
       dst[4] = 0.5f * Dyy;
@@ -638,7 +639,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
         const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
         const float4 q0 = gp[0], q1 = gp[1];
         sg0[tid] = q0;
-        sg1[tid] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, __builtin_amdgcn_rcpf(q0.z));
+        sg1[tid] = stage_conic(q1.x, q1.y, q1.z, __builtin_amdgcn_rcpf(q0.z));
         const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
         const float det = q1.x * q1.z - q1.y * q1.y;
         const float idet = 1.f / det;

@@ -75,7 +75,6 @@ __global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
 
   const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   const size_t inst_base = (size_t)s * a.N;
-  constexpr float LOG2E = 1.4426950408889634f;
   for (int b = start; b < end; b += 64) {
     if (__all(done[0] && done[1] && done[2] && done[3])) break;
     __syncthreads();
@@ -85,7 +84,7 @@ __global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
       const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
       const float4 q1 = gp[1];
       sg0[lane] = gp[0];
-      sg1[lane] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, 0.f);  // exp2 argument (same as the bwd)
+      sg1[lane] = stage_conic(q1.x, q1.y, q1.z, 0.f);  // exp2 argument (same as the bwd)
       const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
 #pragma unroll
       for (int v = 0; v < DV; v++) scol[lane * DV + v] = cp[v];
@@ -153,7 +152,6 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int DV = DP / 4;
-  constexpr float LOG2E = 1.4426950408889634f;
   constexpr int FB = 256;  // splats per batch (forward)
   __shared__ float4 sg0[FB];
   __shared__ float4 sg1[FB];
@@ -191,7 +189,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
       const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
       const float4 q0 = gp[0], q1 = gp[1];
       sg0[tid] = q0;
-      sg1[tid] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, 0.f);
+      sg1[tid] = stage_conic(q1.x, q1.y, q1.z, 0.f);
       // tight box: sigma <= tau, tau = ln(255 opacity) (+ margins); Sigma = conic^-1
       const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
       const float det = q1.x * q1.z - q1.y * q1.y;
@@ -283,7 +281,6 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int DV = DP / 4;
-  constexpr float LOG2E = 1.4426950408889634f;
   constexpr int FB = 256;  // splats per batch: staged indices fit one byte
   __shared__ float4 sg0[FB];
   __shared__ float4 sg1[FB];
@@ -326,7 +323,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
       const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
       const float4 q0 = gp[0], q1 = gp[1];
       sg0[tid] = q0;
-      sg1[tid] = make_float4(q1.x * LOG2E, q1.y * LOG2E, q1.z * LOG2E, 0.f);
+      sg1[tid] = stage_conic(q1.x, q1.y, q1.z, 0.f);
       const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
       const float det = q1.x * q1.z - q1.y * q1.y;
       const float idet = 1.f / det;
