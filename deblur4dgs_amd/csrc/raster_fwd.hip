@@ -362,7 +362,9 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
     __builtin_amdgcn_wave_barrier();
     const int cnt = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
     const int imax = max(max(c0, c1), max(c2, c3));
-    for (int i = 0; i < imax; i++) {
+    for (int i0 = 0; i0 < imax; i0 += 16) {  // every 16 iterations: is the whole wave saturated?
+     const int i1 = min(i0 + 16, imax);
+     for (int i = i0; i < i1; i++) {
       const bool act = i < cnt;
       const int j = act ? (int)mylist[i] : 0;
       const float4 g0 = sg0[j], g1 = sg1[j];
@@ -386,7 +388,8 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
       if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
       T = valid ? nT : T;
       last = valid ? (b + j) : last;
-      if ((i & 15) == 15 && __all(done)) break;
+     }
+     if (__all(done)) break;
     }
   }
 
