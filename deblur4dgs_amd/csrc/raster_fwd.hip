@@ -281,7 +281,8 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int DV = DP / 4;
-  constexpr int FB = 256;  // splats per batch: staged indices fit one byte
+  constexpr int FB = DV > 2 ? 128 : 256;  // splats per batch (indices fit one byte); wide colour records: smaller
+                                           // batches keep 4+ workgroups per CU (measured 17-ch: 0.45 -> 0.42 ms)
   __shared__ float4 sg0[FB];
   __shared__ float4 sg1[FB];
   __shared__ float4 sbox[FB];
