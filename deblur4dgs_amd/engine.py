@@ -321,6 +321,21 @@ def render_instances(cfg: RenderCfg, means, quats, scales, opacities, colors, mo
     """Deform + project + bin + sort + composite all S sub-samples.
     -> render_colors [S,H,W,D'], render_alphas [S,H,W,1], means2d [S,N,2], radii int32 [S,N], state."""
     st = State(cfg)
+    if cfg.N == 0:  # an empty scene (e.g. everything culled): the image is the background, nothing to launch
+        _need_gpu(means)
+        dev, S, H, W = means.device, cfg.S, cfg.height, cfg.width
+        rc = torch.zeros(S, H, W, cfg.NCH, device=dev)
+        if background is not None:
+            rc[..., :cfg.D] = background.to(torch.float32).reshape(-1)[:cfg.D]
+        rc = rc + 0.0 * means.sum()  # keeps the autograd graph connected (all-zero gradients)
+        st.n_isect, st.max_tile = 0, 0
+        st.proj_out = dict(tile_offsets=torch.zeros(S * cfg.tiles[0] * cfg.tiles[1] + 1, dtype=torch.int32, device=dev),
+                           depths=torch.zeros(S, 0, device=dev), conics=torch.zeros(S, 0, 3, device=dev),
+                           opac_act=torch.zeros(0, device=dev), tiles_touched=torch.zeros(S * 0, dtype=torch.int32, device=dev))
+        st.isect = dict(sorted_gid=torch.zeros(0, dtype=torch.int32, device=dev))
+        st.raster = dict(last_ids=torch.zeros(S, H, W, dtype=torch.int32, device=dev))
+        return (rc, torch.zeros(S, H, W, 1, device=dev), torch.zeros(S, 0, 2, device=dev) + 0.0 * means.sum(),
+                torch.zeros(S, 0, dtype=torch.int32, device=dev), st)
     means2d, conics, depths, opac_act, ctab, radii = ProjectFn.apply(
         st, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat, Kmat)
     rc, ra = RasterFn.apply(st, means2d, conics, depths, opac_act, ctab, background)

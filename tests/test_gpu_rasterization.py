@@ -243,6 +243,22 @@ def test_big_splats_and_cull_parameters(scale_mul, radius_clip, near, far):
         assert frac_bad(g[name].grad.cpu(), t[name].grad, 2e-3) < 5e-3, (name, rel_err(g[name].grad.cpu(), t[name].grad))
 
 
+def test_empty_scene_renders_the_background():
+    """N = 0 (everything culled): no launch, background image, empty per-Gaussian outputs, zero-size gradients."""
+    from deblur4dgs_amd.rasterization import rasterization
+
+    dev = torch.device("cuda:0")
+    m = torch.zeros(0, 3, device=dev, requires_grad=True)
+    rc, ra, info = rasterization(m, torch.zeros(0, 4, device=dev), torch.zeros(0, 3, device=dev), torch.zeros(0, device=dev),
+                                 torch.zeros(0, 3, device=dev), torch.eye(4, device=dev)[None],
+                                 torch.tensor([[[50.0, 0, 32], [0, 50.0, 24], [0, 0, 1]]], device=dev), 64, 48,
+                                 backgrounds=torch.tensor([[0.1, 0.2, 0.3]], device=dev), render_mode="RGB+ED")
+    rc.sum().backward()
+    assert rc.shape == (1, 48, 64, 4) and torch.allclose(rc[0, :, :, :3], torch.tensor([0.1, 0.2, 0.3], device=dev).expand(48, 64, 3))
+    assert (rc[..., 3] == 0).all() and (ra == 0).all() and info["n_isect"] == 0 and info["radii"].shape == (1, 0)
+    assert m.grad.shape == (0, 3)
+
+
 def test_single_gaussian_and_api_errors():
     from deblur4dgs_amd.rasterization import rasterization
 
