@@ -157,7 +157,7 @@ def main():
                                   leaves["colors"], 3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                                   leaves["times"], leaves["RTs"], leaves["viewmat"], d["K"], W, H, background=bg,
                                   return_depth=True)
-            loss = (res["blended"] * wimg).sum() + (res["acc"] * wacc).sum()
+            loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
             loss.backward()
         else:
             res = sharder.step(leaves, d["K"], W, H, bg, wimg, wacc)

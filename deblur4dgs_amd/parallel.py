@@ -135,7 +135,7 @@ class ShardedExposure:
                                   leaves["colors"], 3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                                   leaves["times"], leaves["RTs"], leaves["viewmat"], Kmat, W, H, background=background,
                                   return_depth=True)
-            loss = (res["blended"] * wimg).sum() + (res["acc"] * wacc).sum()
+            loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
             loss.backward()
             self.reducer.reduce(leaves, average=True)
             return res["state"]
@@ -147,7 +147,7 @@ class ShardedExposure:
                               leaves["viewmat"], Kmat, W, H, background=background, return_depth=True, blend=False)
         pol = reference_policy(res["renders"].shape[-1])
         blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"][..., 0], own, S, pol, self.group)
-        loss = (blended * wimg).sum() + (acc * wacc).sum()
+        loss = torch.dot(blended.reshape(-1), wimg.reshape(-1)) + torch.dot(acc.reshape(-1), wacc.reshape(-1))
         loss.backward()
         self.reducer.reduce(leaves)
         return res["state"]
