@@ -99,5 +99,5 @@ def render_exposure(
     out = dict(renders=rc, alphas=ra, means2d=means2d, radii=radii, state=st, blended=None, acc=None)
     if blend:
         pol = reference_policy(cfg.NCH) if policy is None else policy
-        out["blended"], out["acc"] = BlendFn.apply(rc, ra[..., 0], pol)
+        out["blended"], out["acc"] = BlendFn.apply(rc, ra.squeeze(-1), pol)  # a view both ways (select would zero-fill + copy)
     return out

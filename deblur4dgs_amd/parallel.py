@@ -146,7 +146,7 @@ class ShardedExposure:
                               leaves["times"].index_select(0, idx), leaves["RTs"].index_select(0, idx),
                               leaves["viewmat"], Kmat, W, H, background=background, return_depth=True, blend=False)
         pol = reference_policy(res["renders"].shape[-1])
-        blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"][..., 0], own, S, pol, self.group)
+        blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), own, S, pol, self.group)
         loss = torch.dot(blended.reshape(-1), wimg.reshape(-1)) + torch.dot(acc.reshape(-1), wacc.reshape(-1))
         loss.backward()
         self.reducer.reduce(leaves)
