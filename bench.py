@@ -112,7 +112,18 @@ def cpu_baseline(name):
         "sample": f"1 of {S} exposure sub-samples of {name} ({N} Gaussians, {W}x{H}), fwd+bwd through the oracle "
                   f"(torch deform + scalar C rasterizer, 1 thread) in {t_sub:.2f} s; value = N / (S * t_sub)",
         "n_isect_sample": ctx["n_isect"],
+        "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
     }
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
