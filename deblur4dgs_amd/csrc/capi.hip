@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" surface of libd4gs.so (declared in include/d4gs.h) and error plumbing.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -49,13 +50,14 @@ struct ProfRec {
   const char *name;
   hipEvent_t a, b;
 };
-bool g_prof_on = false;
+int g_prof_on = 0;  // 0 off, 1 every kernel, 2 only the rasterization kernels (k_raster*)
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
 }  // namespace
 
 ProfScope::ProfScope(const char *name, hipStream_t s) : slot(-1), stream(s) {
   if (!g_prof_on) return;
+  if (g_prof_on == 2 && strncmp(name, "k_raster", 8) != 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.name = name;
@@ -108,7 +110,7 @@ int d4gs_version(void) { return D4GS_VERSION; }
 
 void d4gs_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_on = on != 0;
+  g_prof_on = on;
 }
 
 /* Waits for the recorded events, writes "name count total_ms\n" per kernel into buf, clears the records. */
