@@ -41,6 +41,8 @@ class RenderCfg:
     radius_clip: float = 0.0
     exact_cull: bool = True
     optimistic_sizes: bool = True  # size the intersection lists from the previous call's count, verify afterwards
+    grad_arena: dict | None = None  # optional {"means": tensor, ...}: leaf gradients are written THERE (e.g. views of
+    #                                  a flat all-reduce buffer) instead of fresh tensors; shapes / dtype must match
 
     @property
     def DP(self) -> int:
@@ -158,16 +160,24 @@ class ProjectFn(torch.autograd.Function):
         dims = cfg.dims()
         pi = st.proj_in
         dyn = cfg.G > 0
+        arena = cfg.grad_arena or {}
+
+        def buf(name, *shape):
+            t = arena.get(name)
+            if t is not None and t.shape == torch.Size(shape) and t.dtype == torch.float32 and t.is_contiguous():
+                return t.view(shape)  # a fresh alias: autograd takes it over as the leaf's .grad without a copy
+            return torch.empty(*shape, **f32)
+
         g = dict(
-            v_means=torch.empty(cfg.N, 3, **f32), v_quats=torch.empty(cfg.N, 4, **f32),
-            v_scales=torch.empty(cfg.N, 3, **f32), v_opacities=torch.empty(cfg.N, **f32),
-            v_colors=torch.empty(cfg.N, cfg.D, **f32),
-            v_motion_coefs=torch.empty(cfg.G, cfg.K, **f32) if dyn else None,
-            v_rots=torch.empty(cfg.K, cfg.T, 6, **f32) if dyn else None,
-            v_transls=torch.empty(cfg.K, cfg.T, 3, **f32) if dyn else None,
-            v_times=torch.empty(cfg.S, **f32) if dyn else None,
-            v_RTs=torch.empty(cfg.S, 3, 4, **f32) if pi["RTs"] is not None else None,
-            v_viewmat=torch.empty(4, 4, **f32),
+            v_means=buf("means", cfg.N, 3), v_quats=buf("quats", cfg.N, 4),
+            v_scales=buf("scales", cfg.N, 3), v_opacities=buf("opacities", cfg.N),
+            v_colors=buf("colors", cfg.N, cfg.D),
+            v_motion_coefs=buf("motion_coefs", cfg.G, cfg.K) if dyn else None,
+            v_rots=buf("rots", cfg.K, cfg.T, 6) if dyn else None,
+            v_transls=buf("transls", cfg.K, cfg.T, 3) if dyn else None,
+            v_times=buf("times", cfg.S) if dyn else None,
+            v_RTs=buf("RTs", cfg.S, 3, 4) if pi["RTs"] is not None else None,
+            v_viewmat=buf("viewmat", 4, 4),
             partials=torch.empty(lib.d4gs_bwd_partials_elems(C.byref(dims)), **f32),
         )
         pin, pout = _proj_structs(st)

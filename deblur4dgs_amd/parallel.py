@@ -107,13 +107,14 @@ class FlatGradAllReduce:
             g = leaves[k].grad
             if g is None:
                 self.views[k].zero_()
-            else:
-                self.views[k].copy_(g)
+            elif g.data_ptr() != self.views[k].data_ptr():  # already written in place when the views were passed to
+                self.views[k].copy_(g)                      # the renderer as its `grad_arena`
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         if average:
             self.flat /= dist.get_world_size(self.group)
         for k in self.names:
-            leaves[k].grad = self.views[k]
+            if leaves[k].grad is None or leaves[k].grad.data_ptr() != self.views[k].data_ptr():
+                leaves[k].grad = self.views[k]
 
 
 class ShardedExposure:
@@ -130,11 +131,16 @@ class ShardedExposure:
         S = leaves["times"].shape[0]
         if self.reducer is None:
             self.reducer = FlatGradAllReduce(leaves, self.group)
+        # the renderer writes this step's leaf gradients straight into the flat all-reduce buffer; a .grad that still
+        # aliases it from the previous step must go first (autograd would add the buffer to itself)
+        for k, v in leaves.items():
+            if v.grad is not None and v.grad.data_ptr() == self.reducer.views[k].data_ptr():
+                v.grad = None
         if self.mode == "views":
             res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                   leaves["colors"], 3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                                   leaves["times"], leaves["RTs"], leaves["viewmat"], Kmat, W, H, background=background,
-                                  return_depth=True)
+                                  return_depth=True, grad_arena=self.reducer.views)
             loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
             loss.backward()
             self.reducer.reduce(leaves, average=True)
@@ -144,7 +150,8 @@ class ShardedExposure:
         res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
                               3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                               leaves["times"].index_select(0, idx), leaves["RTs"].index_select(0, idx),
-                              leaves["viewmat"], Kmat, W, H, background=background, return_depth=True, blend=False)
+                              leaves["viewmat"], Kmat, W, H, background=background, return_depth=True, blend=False,
+                              grad_arena=self.reducer.views)
         pol = reference_policy(res["renders"].shape[-1])
         blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), own, S, pol, self.group)
         loss = torch.dot(blended.reshape(-1), wimg.reshape(-1)) + torch.dot(acc.reshape(-1), wacc.reshape(-1))

@@ -119,3 +119,32 @@ def test_track_points_match_oracle():
     assert rel_err(coefs.grad.cpu(), fg["motion_coefs"].grad) < 1e-4
     assert rel_err(rots.grad.cpu(), bases["rots"].grad) < 1e-4
     assert rel_err(transls.grad.cpu(), bases["transls"].grad) < 1e-4
+
+
+def test_grad_arena_receives_the_leaf_gradients_without_copies():
+    """`grad_arena` (used by the view-sharded multi-GPU driver): the projection backward writes the leaf gradients into
+    caller-provided buffers and autograd adopts them as `.grad` - same bits as the default path, same storage."""
+    from deblur4dgs_amd.exposure import render_exposure
+
+    dev = torch.device("cuda:0")
+    sc = make_scene(3000, 3000, 4, 3, 96, 64, seed=11)
+    names = ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls", "times", "RTs", "viewmat")
+
+    def run(arena):
+        L = {k: sc[k].to(dev).clone().requires_grad_() for k in names}
+        res = render_exposure(L["means"], L["quats"], L["scales"], L["opacities"], L["colors"], 3, L["motion_coefs"],
+                              L["rots"], L["transls"], L["times"], L["RTs"], L["viewmat"], sc["K"].to(dev), 96, 64,
+                              return_depth=True, grad_arena=arena)
+        (res["blended"].square().sum() + res["acc"].sum()).backward()
+        return L
+
+    ref = run(None)
+    flat = torch.zeros(sum(sc[k].numel() for k in names), device=dev)
+    arena, off = {}, 0
+    for k in names:
+        arena[k] = flat[off:off + sc[k].numel()].view(sc[k].shape)
+        off += sc[k].numel()
+    got = run(arena)
+    for k in names:
+        assert got[k].grad.data_ptr() == arena[k].data_ptr(), k
+        assert torch.equal(got[k].grad, ref[k].grad), k
