@@ -142,8 +142,10 @@ class ShardedExposure:
                                   leaves["times"], leaves["RTs"], leaves["viewmat"], Kmat, W, H, background=background,
                                   return_depth=True, grad_arena=self.reducer.views)
             loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
-            loss.backward()
-            self.reducer.reduce(leaves, average=True)
+            # data-parallel mean of the per-view gradients: the 1 / world factor rides on the loss, so the SUM
+            # all-reduce needs no 24 MB division pass afterwards
+            (loss * (1.0 / self.world)).backward()
+            self.reducer.reduce(leaves)
             return res["state"]
         own = owned_subsamples(S, self.world, self.rank)
         idx = torch.tensor(own, device=leaves["times"].device, dtype=torch.long)
