@@ -46,6 +46,14 @@ class RasterGrads(C.Structure):
                                  "v_depths", "v_opac_act", "v_ctab")]
 
 
+class Sizes(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects",
+                                         "tiles_touched", "isect_offsets", "tile_counts", "tile_offsets", "n_isect",
+                                         "scan_ws", "render_colors", "render_alphas", "last_ids", "final_T",
+                                         "isect_grad_row", "bwd_partials")] + \
+               [(n, C.c_int32) for n in ("tiles_x", "tiles_y", "channels")]
+
+
 class MoveModelParams(C.Structure):
     _fields_ = [("w", F * 9), ("b", F * 9), ("time_params", F), ("n_time_params", C.c_int32)]
 
@@ -73,7 +81,7 @@ EXPORTS = (
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
     "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_control_stats", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
     "d4gs_pose_encode", "d4gs_move_model_fwd", "d4gs_move_model_bwd",
-    "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_profile_enable", "d4gs_profile_collect",
+    "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_query_sizes", "d4gs_profile_enable", "d4gs_profile_collect",
 )
 
 _lib = None
@@ -113,6 +121,7 @@ def lib() -> C.CDLL:
                                           C.c_int32, P(MoveModelOut), vp]
         L.d4gs_move_model_bwd.argtypes = [P(MoveModelParams), P(MoveModelOut), vp, vp, vp, C.c_int32, C.c_int32,
                                           P(MoveModelGrads), vp]
+        L.d4gs_query_sizes.argtypes = [P(Dims), P(Sizes)]
         L.d4gs_photometric_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         L.d4gs_photometric_blocks.restype = C.c_int64
         L.d4gs_photometric_fwd.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, vp, vp,

@@ -108,6 +108,27 @@ extern "C" {
 
 int d4gs_version(void) { return D4GS_VERSION; }
 
+int d4gs_query_sizes(const D4gsDims *d, D4gsSizes *z) {
+  int rc = check_dims(d);
+  if (rc) return rc;
+  if (!z) {
+    d4gs_set_error("query_sizes: sizes is NULL");
+    return D4GS_EINVAL;
+  }
+  const int64_t N = d->N, S = d->S, SN = S * N, W = d->width, H = d->height;
+  const int64_t tw = (W + D4GS_TILE - 1) / D4GS_TILE, th = (H + D4GS_TILE - 1) / D4GS_TILE;
+  const int64_t nch = d->D + (d->depth_mode != D4GS_DEPTH_NONE ? 1 : 0), DP = (d->D + 3) & ~3;
+  z->means2d = SN * 2, z->depths = SN, z->conics = SN * 3, z->radii = SN, z->opac_act = N, z->ctab = N * DP;
+  z->geom = SN * D4GS_GEOM_STRIDE, z->tile_rects = SN * 2, z->tiles_touched = SN, z->isect_offsets = SN;
+  z->tile_counts = 2 * S * tw * th, z->tile_offsets = S * tw * th + 1, z->n_isect = 2;
+  z->scan_ws = (int64_t)d4gs_scan_ws_elems(SN);
+  z->render_colors = S * H * W * nch, z->render_alphas = S * H * W, z->last_ids = S * H * W, z->final_T = S * H * W;
+  z->isect_grad_row = 6 + nch;
+  z->bwd_partials = (int64_t)d4gs_bwd_partials_elems(d);
+  z->tiles_x = (int32_t)tw, z->tiles_y = (int32_t)th, z->channels = (int32_t)nch;
+  return D4GS_OK;
+}
+
 void d4gs_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on;

@@ -163,6 +163,20 @@ const char *d4gs_last_error(void);
 size_t d4gs_scan_ws_elems(int64_t n_instances);
 size_t d4gs_bwd_partials_elems(const D4gsDims *dims);
 
+/* Element counts of every caller-allocated buffer for one configuration (the "workspace query" of SURVEY 8b): the
+ * per-instance / per-tile buffers of D4gsProjOut, the image buffers of D4gsRaster, and - per intersection, to be
+ * multiplied by the list capacity the caller chooses (see D4gsIsect.n_isect) - the rows of D4gsIsect and of
+ * D4gsRasterGrads.isect_grad.  Element types are the ones of the struct fields. */
+typedef struct {
+  int64_t means2d, depths, conics, radii, opac_act, ctab, geom, tile_rects, tiles_touched, isect_offsets;
+  int64_t tile_counts, tile_offsets, n_isect, scan_ws;          /* D4gsProjOut */
+  int64_t render_colors, render_alphas, last_ids, final_T;       /* D4gsRaster */
+  int64_t isect_grad_row;                                        /* floats per intersection in isect_grad */
+  int64_t bwd_partials;                                          /* D4gsLeafGrads.partials */
+  int32_t tiles_x, tiles_y, channels;                            /* tile grid; D + depth channel */
+} D4gsSizes;
+int d4gs_query_sizes(const D4gsDims *dims, D4gsSizes *sizes);
+
 /* a1-a6 + projection + tile counting + scans.  Replaces params.py:39-43,142-180, transforms.py:41-53,
  * scene_model.py:67-120,352-353 and gsplat fully_fused_projection_fwd + isect_tiles pass 1 for all S. */
 int d4gs_project_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, void *stream);

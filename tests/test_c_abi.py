@@ -74,3 +74,27 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             txt = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), fn
+
+
+def test_query_sizes_is_a_pure_host_call(lib):
+    """d4gs_query_sizes (the workspace query of SURVEY 8b) needs no GPU: element counts of every caller-owned buffer."""
+    from deblur4dgs_amd import _lib as L
+
+    lib.d4gs_query_sizes.argtypes = [C.POINTER(L.Dims), C.POINTER(L.Sizes)]
+    d = L.Dims(N=1000, G=400, K=6, T=24, S=8, D=3, width=100, height=50, depth_mode=L.DEPTH_ED)
+    z = L.Sizes()
+    assert lib.d4gs_query_sizes(C.byref(d), C.byref(z)) == 0
+    SN, tw, th = 8 * 1000, 7, 4
+    assert (z.tiles_x, z.tiles_y, z.channels) == (tw, th, 4)
+    assert (z.means2d, z.depths, z.conics, z.radii) == (SN * 2, SN, SN * 3, SN)
+    assert (z.opac_act, z.ctab, z.geom) == (1000, 1000 * 4, SN * L.GEOM_STRIDE)
+    assert (z.tile_rects, z.tiles_touched, z.isect_offsets) == (SN * 2, SN, SN)
+    assert (z.tile_counts, z.tile_offsets, z.n_isect) == (2 * 8 * tw * th, 8 * tw * th + 1, 2)
+    assert z.render_colors == 8 * 50 * 100 * 4 and z.render_alphas == z.last_ids == z.final_T == 8 * 50 * 100
+    assert z.isect_grad_row == 6 + 4
+    lib.d4gs_scan_ws_elems.restype = C.c_size_t
+    lib.d4gs_scan_ws_elems.argtypes = [C.c_int64]
+    lib.d4gs_bwd_partials_elems.restype = C.c_size_t
+    assert z.scan_ws == lib.d4gs_scan_ws_elems(SN) and z.bwd_partials == lib.d4gs_bwd_partials_elems(C.byref(d))
+    bad = L.Dims(N=10, G=20, K=1, T=1, S=1, D=3, width=16, height=16)
+    assert lib.d4gs_query_sizes(C.byref(bad), C.byref(z)) == -1 and lib.d4gs_query_sizes(C.byref(d), None) == -1
