@@ -431,3 +431,28 @@ torch.save([t[k].grad.cpu() for k in ("means", "quats", "scales", "opac", "color
     for other in outs[1:]:
         for x, y in zip(outs[0], other):
             assert rel_err(y, x) < 2e-5, rel_err(y, x)
+
+
+def test_engine_allocations_match_query_sizes():
+    """The Python driver and d4gs_query_sizes (what a non-PyTorch host would allocate) agree buffer by buffer."""
+    import ctypes as C
+
+    from deblur4dgs_amd import _lib as L
+    from deblur4dgs_amd.exposure import render_exposure
+    from deblur4dgs_amd.synth import make_scene
+
+    dev = torch.device("cuda:0")
+    sc = make_scene(1234, 700, 5, 3, 100, 70, seed=4)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
+    res = render_exposure(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], 3, t["motion_coefs"], t["rots"],
+                          t["transls"], t["times"], t["RTs"], t["viewmat"], t["K"], 100, 70, return_depth=True)
+    st = res["state"]
+    z = L.Sizes()
+    d = st.cfg.dims()
+    assert L.lib().d4gs_query_sizes(C.byref(d), C.byref(z)) == 0
+    for name in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects", "tiles_touched",
+                 "isect_offsets", "tile_counts", "tile_offsets", "n_isect", "scan_ws"):
+        assert st.proj_out[name].numel() == getattr(z, name), name
+    for name in ("render_colors", "render_alphas", "last_ids", "final_T"):
+        assert st.raster[name].numel() == getattr(z, name), name
+    assert z.isect_grad_row == 6 + st.cfg.NCH and (z.tiles_x, z.tiles_y) == st.cfg.tiles
