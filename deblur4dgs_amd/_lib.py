@@ -63,7 +63,7 @@ class MoveModelOut(C.Structure):
 
 
 class MoveModelGrads(C.Structure):
-    _fields_ = [("v_w", F * 9), ("v_b", F * 9), ("v_time_params", F), ("v_delta", F)]
+    _fields_ = [("v_w", F * 9), ("v_b", F * 9), ("v_time_params", F), ("v_delta", F), ("v_enc", F)]
 
 
 class LeafGrads(C.Structure):
@@ -80,7 +80,7 @@ EXPORTS = (
     "d4gs_version", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
     "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_control_stats", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
-    "d4gs_pose_encode", "d4gs_move_model_fwd", "d4gs_move_model_bwd",
+    "d4gs_pose_encode", "d4gs_pose_encode_bwd", "d4gs_move_model_fwd", "d4gs_move_model_bwd",
     "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_query_sizes", "d4gs_profile_enable", "d4gs_profile_collect",
 )
 
@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
         L.d4gs_camera_path_fwd.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_float, vp, vp, vp, vp, vp, vp]
         L.d4gs_camera_path_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.d4gs_pose_encode.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp]
+        L.d4gs_pose_encode_bwd.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, vp, vp]
         L.d4gs_move_model_fwd.argtypes = [vp, C.c_int32, vp, C.c_int32, P(MoveModelParams), C.c_int32, C.c_int32, C.c_float,
                                           C.c_int32, P(MoveModelOut), vp]
         L.d4gs_move_model_bwd.argtypes = [P(MoveModelParams), P(MoveModelOut), vp, vp, vp, C.c_int32, C.c_int32,
@@ -130,8 +131,8 @@ def lib() -> C.CDLL:
                                            C.c_float, vp, vp]
         L.d4gs_blend_fwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp]
         L.d4gs_blend_bwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp, vp, vp]
-        if L.d4gs_version() != 100:
-            raise RuntimeError(f"libd4gs.so version {L.d4gs_version()} != 100 (stale build?)")
+        if L.d4gs_version() != 200:
+            raise RuntimeError(f"libd4gs.so version {L.d4gs_version()} != 200 (stale build?)")
         _lib = L
     return _lib
 

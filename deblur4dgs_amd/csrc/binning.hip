@@ -290,11 +290,8 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   const int n_tiles = dims->S * e.tw * e.th;
   // Three size classes, one launch each (a workgroup exits at once if its list is not in the class): short lists
   // sort with 16 KB of LDS (8+ workgroups / CU), long ones with up to 128 KB, anything longer in global memory.
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-    attr_set = true;
-  }
+  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
+  (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
   const int classes[3][2] = {{0, 2048}, {2048, 16384}, {16384, -1}};
   for (int c = 0; c < 3; c++) {
     const int64_t longest = isect->max_tile_count > 0 ? isect->max_tile_count : isect->n_isect;

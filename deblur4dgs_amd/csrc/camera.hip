@@ -42,6 +42,14 @@ __device__ inline Dual Sqrt(Dual a) {
 __device__ inline Dual Sin(Dual a) { return {sinf(a.v), cosf(a.v) * a.d}; }
 __device__ inline Dual Cos(Dual a) { return {cosf(a.v), -sinf(a.v) * a.d}; }
 __device__ inline Dual Atan(Dual a) { return {atanf(a.v), a.d / (1.f + a.v * a.v)}; }
+__device__ inline Dual Acos(Dual a) { return {acosf(a.v), -a.d / sqrtf(1.f - a.v * a.v)}; }
+__device__ inline float Acos(float a) { return acosf(a); }
+// torch.clamp: the gradient passes on the closed interval
+__device__ inline Dual Clamp(Dual a, float lo, float hi) { return {fminf(fmaxf(a.v, lo), hi), (a.v >= lo && a.v <= hi) ? a.d : 0.f}; }
+__device__ inline float Clamp(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
+// `theta % math.pi` for theta = acos(.) >= 0: slope 1
+__device__ inline Dual Fmod(Dual a, float m) { return {fmodf(a.v, m), a.d}; }
+__device__ inline float Fmod(float a, float m) { return fmodf(a, m); }
 
 // plain floats through the same templates (pose encoding carries no tangent)
 __device__ inline float mkT(float v, float *) { return v; }
@@ -245,32 +253,37 @@ __global__ void k_camera_path_bwd(const float *__restrict__ jac, const float *__
   }
 }
 
-// ---- pose encoding (no tangent): SE3_to_se3 + positional embedding -----------------------------------------
+// ---- pose encoding: SE3_to_se3 + positional embedding -----------------------------------------------------
+// MoveModel.preprocessPose (spline_utils.py:177-195) on plain floats (forward) or dual numbers (input gradient)
+template <typename T>
+__device__ inline void pose_to_se3(const T *R, const T *Tv, T *x) {
+  // SO3_to_so3 (spline_utils.py:177-184)
+  T trace = R[0] + R[4] + R[8];
+  T c = Clamp((trace - 1.f) / 2.f, -1.f + 1e-7f, 1.f - 1e-7f);
+  T theta = Fmod(Acos(c), 3.14159265358979323846f);
+  T A = taylor(theta, 0);
+  T f = 1.f / (2.f * A + 1e-8f);
+  V3<T> w = {f * (R[7] - R[5]), f * (R[2] - R[6]), f * (R[3] - R[1])};
+  // SE3_to_se3 (spline_utils.py:187-195)
+  M3<T> wx = skew(w), wx2 = matmul(wx, wx);
+  T th = norm3(w);
+  T A2 = taylor(th, 0), B2 = taylor(th, 1);
+  T cc = (1.f - A2 / (2.f * B2)) / (th * th + 1e-8f);
+  M3<T> invV = eye_plus(1.f, mkT(-0.5f, (T *)nullptr), wx, cc, wx2);
+  V3<T> tv = {Tv[0], Tv[1], Tv[2]};
+  V3<T> u = matvec(invV, tv);
+  x[0] = w.x, x[1] = w.y, x[2] = w.z, x[3] = u.x, x[4] = u.y, x[5] = u.z;
+}
+
 __global__ void k_pose_encode(const float *__restrict__ Rp, int r_stride, const float *__restrict__ Tp, int t_stride,
                               float *__restrict__ enc) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float R[9], T[3];
+  float R[9], T[3], x[6];
   for (int i = 0; i < 3; ++i) {
     T[i] = Tp[i * t_stride];
     for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rp[i * r_stride + j];
   }
-  // SO3_to_so3 (spline_utils.py:177-184)
-  float trace = R[0] + R[4] + R[8];
-  float c = fminf(fmaxf((trace - 1.f) / 2.f, -1.f + 1e-7f), 1.f - 1e-7f);
-  float theta = acosf(c);
-  theta = fmodf(theta, 3.14159265358979323846f);  // `% math.pi`, acos >= 0
-  float A = taylor(theta, 0);
-  float f = 1.f / (2.f * A + 1e-8f);
-  V3<float> w = {f * (R[7] - R[5]), f * (R[2] - R[6]), f * (R[3] - R[1])};
-  // SE3_to_se3 (spline_utils.py:187-195)
-  M3<float> wx = skew(w), wx2 = matmul(wx, wx);
-  float th = Sqrt(w.x * w.x + w.y * w.y + w.z * w.z);
-  float A2 = taylor(th, 0), B2 = taylor(th, 1);
-  float cc = (1.f - A2 / (2.f * B2)) / (th * th + 1e-8f);
-  M3<float> invV = eye_plus(1.f, -0.5f, wx, cc, wx2);
-  V3<float> tv = {T[0], T[1], T[2]};
-  V3<float> u = matvec(invV, tv);
-  float x[6] = {w.x, w.y, w.z, u.x, u.y, u.z};
+  pose_to_se3(R, T, x);
   // move_model.py:12-63: [x, sin(x f), cos(x f)] for f = 1, 2, 4, 8, 16
   for (int k = 0; k < 6; ++k) enc[k] = x[k];
   float fr = 1.f;
@@ -279,6 +292,31 @@ __global__ void k_pose_encode(const float *__restrict__ Rp, int r_stride, const 
       enc[6 + 12 * l + k] = sinf(x[k] * fr);
       enc[6 + 12 * l + 6 + k] = cosf(x[k] * fr);
     }
+}
+
+// Input gradient of the pose encoding (test-time pose refinement differentiates the render w.r.t. w2c, which also
+// feeds this module: flow3d/validator.py:442-448 -> scene_model.py:249-256).  Thread j < 12 re-evaluates
+// SE3_to_se3 in dual numbers with the tangent of input j (R row-major 0..8, T 9..11) and contracts it with the
+// embedding's adjoint: v_in[j] = sum_k (v_enc[k] + sum_l f_l (cos(x_k f_l) v_sin - sin(x_k f_l) v_cos)) dx_k/d in_j.
+__global__ void k_pose_encode_bwd(const float *__restrict__ Rp, int r_stride, const float *__restrict__ Tp, int t_stride,
+                                  const float *__restrict__ v_enc, float *__restrict__ v_R, float *__restrict__ v_T) {
+  const int j = threadIdx.x;
+  if (j >= 12 || blockIdx.x != 0) return;
+  Dual R[9], T[3], x[6];
+  for (int i = 0; i < 3; ++i) {
+    T[i] = mk(Tp[i * t_stride], j == 9 + i ? 1.f : 0.f);
+    for (int c = 0; c < 3; ++c) R[i * 3 + c] = mk(Rp[i * r_stride + c], j == i * 3 + c ? 1.f : 0.f);
+  }
+  pose_to_se3(R, T, x);
+  float acc = 0.f;
+  for (int k = 0; k < 6; ++k) {
+    float vx = v_enc[k], fr = 1.f;
+    for (int l = 0; l < 5; ++l, fr *= 2.f)
+      vx += fr * (cosf(x[k].v * fr) * v_enc[6 + 12 * l + k] - sinf(x[k].v * fr) * v_enc[6 + 12 * l + 6 + k]);
+    acc += vx * x[k].d;
+  }
+  if (j < 9) v_R[j] = acc;
+  else v_T[j - 9] = acc;
 }
 
 // ---- the MoveModel MLP (move_model.py:66-110): 66 -> 64 x4 (LeakyReLU 0.01) -> 64, two heads 64 -> 64 -> 6 ---------
@@ -351,9 +389,10 @@ __device__ __forceinline__ void mlp_layer_bwd(const float *__restrict__ W, const
 }
 
 __global__ void __launch_bounds__(256) k_move_mlp_bwd(const float *__restrict__ acts, MlpPtrs p, const float *__restrict__ v_delta0,
-                                                      const float *__restrict__ v_delta1, MlpGradPtrs g) {
+                                                      const float *__restrict__ v_delta1, MlpGradPtrs g,
+                                                      float *__restrict__ v_enc) {
   __shared__ float sx[MLP_ACTS];
-  __shared__ float va[64], vb[64], vd[12];
+  __shared__ float va[64], vb[64], vd[12], ve[MLP_IN];
   for (int i = threadIdx.x; i < MLP_ACTS; i += 256) sx[i] = acts[i];
   if (threadIdx.x < 6) vd[threadIdx.x] = v_delta0[threadIdx.x];
   else if (threadIdx.x < 12) vd[threadIdx.x] = v_delta1[threadIdx.x - 6];
@@ -369,7 +408,8 @@ __global__ void __launch_bounds__(256) k_move_mlp_bwd(const float *__restrict__ 
   mlp_layer_bwd(p.w[3], va, a3, 64, 64, g.w[3], g.b[3], vb, false, true);
   mlp_layer_bwd(p.w[2], vb, a2, 64, 64, g.w[2], g.b[2], va, false, true);
   mlp_layer_bwd(p.w[1], va, a1, 64, 64, g.w[1], g.b[1], vb, false, true);
-  mlp_layer_bwd(p.w[0], vb, sx, MLP_IN, 64, g.w[0], g.b[0], nullptr, false, false);
+  mlp_layer_bwd(p.w[0], vb, sx, MLP_IN, 64, g.w[0], g.b[0], v_enc ? ve : nullptr, false, false);
+  if (v_enc && threadIdx.x < MLP_IN) v_enc[threadIdx.x] = ve[threadIdx.x];
 }
 
 }  // namespace
@@ -379,6 +419,13 @@ int d4gs_pose_encode_impl(const float *R, int32_t r_stride, const float *T, int3
   ProfScope ps("k_pose_encode", stream);
   k_pose_encode<<<1, 64, 0, stream>>>(R, r_stride, T, t_stride, enc);
   return d4gs_check_launch("k_pose_encode");
+}
+
+int d4gs_pose_encode_bwd_impl(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const float *v_enc,
+                              float *v_R, float *v_T, hipStream_t stream) {
+  ProfScope ps("k_pose_encode_bwd", stream);
+  k_pose_encode_bwd<<<1, 64, 0, stream>>>(R, r_stride, T, t_stride, v_enc, v_R, v_T);
+  return d4gs_check_launch("k_pose_encode_bwd");
 }
 
 int d4gs_camera_path_fwd_impl(const float *delta0, const float *delta1, int32_t S, const float *time_params,
@@ -422,7 +469,8 @@ int d4gs_move_model_fwd_impl(const float *R, int32_t r_stride, const float *T, i
 int d4gs_move_model_bwd_impl(const float *jac, const float *dtimes, const float *deltaT, const float *acts,
                              const float *const *w, const float *const *b, const float *v_RTs, const float *v_times,
                              const float *v_deltaT, int32_t S, int32_t index, int32_t n_time_params, float *v_delta,
-                             float *const *v_w, float *const *v_b, float *v_time_params, hipStream_t stream) {
+                             float *const *v_w, float *const *v_b, float *v_time_params, float *v_enc,
+                             hipStream_t stream) {
   int rc = d4gs_camera_path_bwd_impl(jac, dtimes, deltaT, v_RTs, v_times, v_deltaT, S, index, n_time_params, v_delta,
                                      v_delta + 6, v_time_params, stream);
   if (rc) return rc;
@@ -430,6 +478,6 @@ int d4gs_move_model_bwd_impl(const float *jac, const float *dtimes, const float 
   MlpGradPtrs g;
   for (int l = 0; l < 9; l++) p.w[l] = w[l], p.b[l] = b[l], g.w[l] = v_w[l], g.b[l] = v_b[l];
   ProfScope ps("k_move_mlp_bwd", stream);
-  k_move_mlp_bwd<<<1, 256, 0, stream>>>(acts, p, v_delta, v_delta + 6, g);
+  k_move_mlp_bwd<<<1, 256, 0, stream>>>(acts, p, v_delta, v_delta + 6, g, v_enc);
   return d4gs_check_launch("k_move_mlp_bwd");
 }

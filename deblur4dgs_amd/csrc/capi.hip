@@ -32,7 +32,8 @@ int d4gs_move_model_fwd_impl(const float *, int32_t, const float *, int32_t, con
                              float *, float *, float *, hipStream_t);
 int d4gs_move_model_bwd_impl(const float *, const float *, const float *, const float *, const float *const *,
                              const float *const *, const float *, const float *, const float *, int32_t, int32_t, int32_t,
-                             float *, float *const *, float *const *, float *, hipStream_t);
+                             float *, float *const *, float *const *, float *, float *, hipStream_t);
+int d4gs_pose_encode_bwd_impl(const float *, int32_t, const float *, int32_t, const float *, float *, float *, hipStream_t);
 
 int d4gs_photometric_fwd_impl(const float *, const float *, const float *, int32_t, int32_t, int32_t, float, float, float *,
                               float *, float *, hipStream_t);
@@ -181,9 +182,23 @@ int d4gs_project_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
   return d4gs_project_fwd_impl(dims, in, out, (hipStream_t)stream);
 }
 
+static int check_binned(const char *who, const D4gsProjOut *proj, const D4gsIsect *isect) {
+  if (!proj || !isect || !proj->geom || !proj->ctab || !proj->depths || !proj->tile_rects || !proj->tiles_touched ||
+      !proj->isect_offsets || !proj->tile_counts || !proj->tile_offsets || !proj->n_isect) {
+    d4gs_set_error("%s: NULL projection buffer", who);
+    return D4GS_EINVAL;
+  }
+  if (isect->n_isect > 0 && (!isect->keys || !isect->gid_of_emit || !isect->sorted_gid || !isect->sorted_emit)) {
+    d4gs_set_error("%s: NULL intersection list", who);
+    return D4GS_EINVAL;
+  }
+  return D4GS_OK;
+}
+
 int d4gs_bin_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, void *stream) {
   int rc = check_dims(dims);
   if (rc) return rc;
+  if ((rc = check_binned("d4gs_bin_sort", proj, isect))) return rc;
   return d4gs_bin_sort_impl(dims, proj, isect, (hipStream_t)stream);
 }
 
@@ -191,6 +206,11 @@ int d4gs_raster_fwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
                     void *stream) {
   int rc = check_dims(dims);
   if (rc) return rc;
+  if ((rc = check_binned("d4gs_raster_fwd", proj, isect))) return rc;
+  if (!r || !r->render_colors || !r->render_alphas || !r->last_ids || !r->final_T) {
+    d4gs_set_error("d4gs_raster_fwd: NULL output buffer");
+    return D4GS_EINVAL;
+  }
   return d4gs_raster_fwd_impl(dims, proj, isect, r, (hipStream_t)stream);
 }
 
@@ -198,6 +218,12 @@ int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
                     const D4gsRasterGrads *g, void *stream) {
   int rc = check_dims(dims);
   if (rc) return rc;
+  if ((rc = check_binned("d4gs_raster_bwd", proj, isect))) return rc;
+  if (!r || !r->render_colors || !r->render_alphas || !r->last_ids || !r->final_T || !g || !g->v_render_colors ||
+      !g->isect_grad || !g->v_means2d || !g->v_conics || !g->v_depths || !g->v_opac_act || !g->v_ctab) {
+    d4gs_set_error("d4gs_raster_bwd: NULL forward state or gradient buffer");
+    return D4GS_EINVAL;
+  }
   return d4gs_raster_bwd_impl(dims, proj, isect, r, g, (hipStream_t)stream);
 }
 
@@ -206,6 +232,18 @@ int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
                      const D4gsLeafGrads *grads, void *stream) {
   int rc = check_dims(dims);
   if (rc) return rc;
+  if (!in || !proj || !grads || !in->means || !in->quats || !in->scales || !in->opacities || !in->colors || !in->viewmat ||
+      !in->Kmat || !proj->radii || !proj->conics || !proj->ctab || !proj->opac_act || !v_means2d || !v_conics ||
+      !v_depths || !v_opac_act || !v_ctab || !grads->v_means || !grads->v_quats || !grads->v_scales ||
+      !grads->v_opacities || !grads->v_colors || !grads->partials) {
+    d4gs_set_error("d4gs_project_bwd: NULL required buffer");
+    return D4GS_EINVAL;
+  }
+  if (dims->G > 0 && (!in->motion_coefs || !in->rots || !in->transls || !in->times || !grads->v_motion_coefs ||
+                      !grads->v_rots || !grads->v_transls)) {
+    d4gs_set_error("d4gs_project_bwd: G>0 needs motion_coefs/rots/transls/times and their gradient buffers");
+    return D4GS_EINVAL;
+  }
   return d4gs_project_bwd_impl(dims, in, proj, v_means2d, v_conics, v_depths, v_opac_act, v_ctab, grads,
                                (hipStream_t)stream);
 }
@@ -223,6 +261,10 @@ static int check_points(const D4gsDims *d, const D4gsProjIn *in) {
 int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points, void *stream) {
   int rc = check_points(dims, in);
   if (rc) return rc;
+  if (!points) {
+    d4gs_set_error("d4gs_points_fwd: NULL output");
+    return D4GS_EINVAL;
+  }
   return d4gs_points_fwd_impl(dims, in, points, (hipStream_t)stream);
 }
 
@@ -230,6 +272,11 @@ int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_p
                     void *stream) {
   int rc = check_points(dims, in);
   if (rc) return rc;
+  if (!v_points || !grads || !grads->v_means || !grads->partials ||
+      (dims->G > 0 && (!grads->v_motion_coefs || !grads->v_rots || !grads->v_transls))) {
+    d4gs_set_error("d4gs_points_bwd: NULL gradient buffer");
+    return D4GS_EINVAL;
+  }
   return d4gs_points_bwd_impl(dims, in, v_points, grads, (hipStream_t)stream);
 }
 
@@ -323,7 +370,17 @@ int d4gs_move_model_bwd(const D4gsMoveModelParams *p, const D4gsMoveModelOut *o,
       return D4GS_EINVAL;
     }
   return d4gs_move_model_bwd_impl(o->jac, o->dtimes, o->deltaT, o->acts, p->w, p->b, v_RTs, v_times, v_deltaT, S, index,
-                                  p->n_time_params, g->v_delta, g->v_w, g->v_b, g->v_time_params, (hipStream_t)stream);
+                                  p->n_time_params, g->v_delta, g->v_w, g->v_b, g->v_time_params, g->v_enc,
+                                  (hipStream_t)stream);
+}
+
+int d4gs_pose_encode_bwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const float *v_enc,
+                         float *v_R, float *v_T, void *stream) {
+  if (!R || !T || !v_enc || !v_R || !v_T || r_stride < 3 || t_stride < 1) {
+    d4gs_set_error("pose_encode_bwd: NULL buffer or bad stride (r_stride=%d t_stride=%d)", r_stride, t_stride);
+    return D4GS_EINVAL;
+  }
+  return d4gs_pose_encode_bwd_impl(R, r_stride, T, t_stride, v_enc, v_R, v_T, (hipStream_t)stream);
 }
 
 int d4gs_photometric_fwd(const float *pred, const float *gt, const float *mask, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -510,11 +510,8 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
     d4gs_set_error("project_bwd: LDS budget exceeded (S=%d K=%d)", dims->S, dims->K);
     return D4GS_EINVAL;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_project_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
+  (void)hipFuncSetAttribute((const void *)k_project_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int blocks = (dims->N + BLK - 1) / BLK;
   D4GS_LAUNCH("k_project_bwd", k_project_bwd, dim3(blocks), dim3(BLK), lds, stream, a);
   int rc = d4gs_check_launch("k_project_bwd");

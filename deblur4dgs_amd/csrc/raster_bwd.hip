@@ -846,7 +846,8 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
     D4GS_CASE(8)
     D4GS_CASE(16)
     default:
-      d4gs_set_error("unsupported colour channel count D=%d", dims->D);
+      d4gs_set_error("unsupported colour channel count D=%d (instantiated: 1,2,3,4,5,8,16; render wider colour "
+                     "vectors in chunks over the same projection / tile lists)", dims->D);
       return D4GS_EINVAL;
   }
 #undef D4GS_CASE

@@ -447,9 +447,9 @@ int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
     D4GS_CASE(5)
     D4GS_CASE(8)
     D4GS_CASE(16)
-    D4GS_CASE(32)
     default:
-      d4gs_set_error("unsupported colour channel count D=%d (supported: 1,2,3,4,5,8,16,32; pad on the host)", dims->D);
+      d4gs_set_error("unsupported colour channel count D=%d (instantiated: 1,2,3,4,5,8,16; render wider colour "
+                     "vectors in chunks over the same projection / tile lists)", dims->D);
       return D4GS_EINVAL;
   }
 #undef D4GS_CASE

@@ -14,8 +14,10 @@ There is no eager / CPU fallback: tensors must live on a ROCm device.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
-from dataclasses import dataclass, field
+import threading
+from dataclasses import dataclass, field, replace
 
 import torch
 
@@ -63,7 +65,9 @@ class RenderCfg:
 
 @dataclass
 class State:
-    """Non-differentiable buffers shared by the two stages (all owned by torch)."""
+    """Non-differentiable buffers shared by the stages (all owned by torch).  One projection + one binning / depth sort
+    serve every channel chunk of a render (`raster` is the first chunk's composite state; `last_ids`, `final_T` and the
+    alphas are the same for all chunks)."""
     cfg: RenderCfg
     proj_in: dict = field(default_factory=dict)
     proj_out: dict = field(default_factory=dict)
@@ -71,25 +75,69 @@ class State:
     raster: dict = field(default_factory=dict)
     n_isect: int = -1
     max_tile: int = -1
+    binned: bool = False
+
+
+SUPPORTED_D = (1, 2, 3, 4, 5, 8, 16)  # colour-channel instantiations of the composite kernels (+ optional depth)
+
+
+def channel_chunks(D: int) -> list[tuple[int, int, int]]:
+    """[(first channel, end channel, kernel width)]: any channel count is rendered as chunks of <= 16 channels that
+    share the projection and the sorted tile lists (gsplat's `channel_chunk` idea); a ragged last chunk is zero-padded
+    to the next instantiated width.  The depth channel, if any, rides on the last chunk."""
+    out, c = [], 0
+    while D - c > SUPPORTED_D[-1]:
+        out.append((c, c + SUPPORTED_D[-1], SUPPORTED_D[-1]))
+        c += SUPPORTED_D[-1]
+    out.append((c, D, next(d for d in SUPPORTED_D if d >= max(D - c, 1))))
+    return out
 
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_SIZE_GUESS: dict = {}                     # (device, S, N, W, H) -> (list capacity, bound on the longest tile list)
+# (device, S, W, H, N bucket) -> (list capacity, bound on the longest tile list).  N is bucketed to its two leading bits
+# so that densification (N changes every control step) reuses the entry; bounded LRU; guarded by a lock because the
+# reference's viewer thread renders concurrently with training (flow3d/trainer.py:204-207).
+_SIZE_GUESS: "collections.OrderedDict" = collections.OrderedDict()
+_SIZE_GUESS_MAX = 64
+_SIZE_LOCK = threading.Lock()
 _SIZE_STATS = {"calls": 0, "relaunched": 0}
 _PINNED: dict = {}
 
 
-def _pinned_counts(dev):
-    """One pinned int64[2] per (thread, device): every use is followed by an event wait before the next one."""
-    import threading
+def _size_key(dev, S, N, W, H):
+    shift = max(N.bit_length() - 2, 0)
+    return (dev.index, S, W, H, (N >> shift) << shift)
 
-    k = (threading.get_ident(), dev.index)
-    if k not in _PINNED:
-        _PINNED[k] = torch.empty(2, dtype=torch.int64).pin_memory()
-    return _PINNED[k]
+
+def _guess_get(key):
+    with _SIZE_LOCK:
+        g = _SIZE_GUESS.get(key)
+        if g is not None:
+            _SIZE_GUESS.move_to_end(key)
+        return g
+
+
+def _guess_put(key, val):
+    with _SIZE_LOCK:
+        _SIZE_GUESS[key] = val
+        _SIZE_GUESS.move_to_end(key)
+        while len(_SIZE_GUESS) > _SIZE_GUESS_MAX:
+            _SIZE_GUESS.popitem(last=False)
+
+
+def _pinned_counts(dev):
+    """One pinned int64[2] per (thread, device, stream): every use is followed by an event wait before the next one on
+    that stream, and two streams of one thread never share a buffer."""
+    k = (threading.get_ident(), dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    with _SIZE_LOCK:
+        if k not in _PINNED:
+            if len(_PINNED) > 256:
+                _PINNED.clear()
+            _PINNED[k] = torch.empty(2, dtype=torch.int64).pin_memory()
+        return _PINNED[k]
 
 
 def _need_gpu(t: torch.Tensor):
@@ -105,6 +153,10 @@ def _proj_structs(st: State):
     pin = L.fill(L.ProjIn(), **st.proj_in)
     pout = L.fill(L.ProjOut(), **st.proj_out)
     return pin, pout
+
+
+_PROJ_IN = ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls", "times", "RTs", "viewmat",
+            "Kmat")
 
 
 class ProjectFn(torch.autograd.Function):
@@ -137,6 +189,11 @@ class ProjectFn(torch.autograd.Function):
         pin, pout = _proj_structs(st)
         L.check(lib.d4gs_project_fwd(C.byref(dims), C.byref(pin), C.byref(pout), _stream()), "d4gs_project_fwd")
         ctx.st = st
+        # The backward re-reads the leaves.  `_f32c` hands out detached ALIASES of f32-contiguous leaves, which share the
+        # leaf's version counter: routing them through save_for_backward makes an in-place update between forward and
+        # backward (optimizer.step, reset_opacities' fill_, a control step) raise, as stock autograd / gsplat would,
+        # instead of silently differentiating modified parameters.
+        ctx.save_for_backward(*[st.proj_in[k] for k in _PROJ_IN])
         ctx.needs = [t is not None and t.requires_grad for t in
                      (means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat)]
         o = st.proj_out
@@ -158,7 +215,7 @@ class ProjectFn(torch.autograd.Function):
         v_opac_act, v_ctab = z(v_opac_act, o["opac_act"]), z(v_ctab, o["ctab"])
         lib = L.lib()
         dims = cfg.dims()
-        pi = st.proj_in
+        pi = dict(zip(_PROJ_IN, ctx.saved_tensors))  # raises if a leaf was modified in place since the forward
         dyn = cfg.G > 0
         arena = cfg.grad_arena or {}
 
@@ -180,7 +237,8 @@ class ProjectFn(torch.autograd.Function):
             v_viewmat=buf("viewmat", 4, 4),
             partials=torch.empty(lib.d4gs_bwd_partials_elems(C.byref(dims)), **f32),
         )
-        pin, pout = _proj_structs(st)
+        pin = L.fill(L.ProjIn(), **pi)
+        pout = L.fill(L.ProjOut(), **st.proj_out)
         lg = L.fill(L.LeafGrads(), **g)
         vp = lambda t: C.c_void_p(L.ptr(t))  # bare Python ints would be truncated to 32-bit C ints
         L.check(lib.d4gs_project_bwd(C.byref(dims), C.byref(pin), C.byref(pout), vp(v_means2d), vp(v_conics),
@@ -193,20 +251,31 @@ class ProjectFn(torch.autograd.Function):
 
 
 class RasterFn(torch.autograd.Function):
+    """Composite one channel chunk.  `cfg` is the chunk's configuration (its D = the kernel width, depth mode set on
+    the last chunk only); the projection outputs and the sorted tile lists come from the shared `st`.  The first chunk
+    of a render bins + sorts (st.binned)."""
+
     @staticmethod
-    def forward(ctx, st: State, means2d, conics, depths, opac_act, ctab, background):
-        cfg = st.cfg
+    def forward(ctx, st: State, cfg: RenderCfg, means2d, conics, depths, opac_act, ctab, background):
         dev = means2d.device
         S, H, W = cfg.S, cfg.height, cfg.width
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         lib = L.lib()
-        st.raster = dict(background=_f32c(background), render_colors=torch.empty(S, H, W, cfg.NCH, **f32),
-                         render_alphas=torch.empty(S, H, W, **f32), last_ids=torch.empty(S, H, W, **i32),
-                         final_T=torch.empty(S, H, W, **f32))
+        ctab = ctab.detach().to(torch.float32).contiguous()
+        assert ctab.shape == (cfg.N, cfg.DP)
+        rst = dict(background=_f32c(background), render_colors=torch.empty(S, H, W, cfg.NCH, **f32),
+                   render_alphas=torch.empty(S, H, W, **f32), last_ids=torch.empty(S, H, W, **i32),
+                   final_T=torch.empty(S, H, W, **f32))
         dims = cfg.dims()
-        _, pout = _proj_structs(st)
-        ras = L.fill(L.Raster(), **st.raster)
+        pout = L.fill(L.ProjOut(), **{**st.proj_out, "ctab": ctab})
+        ras = L.fill(L.Raster(), **rst)
+
+        def raster(cap, max_hint):
+            isect = L.fill(L.Isect(), **st.isect)
+            isect.n_isect, isect.max_tile_count = max(cap, 1), max_hint
+            L.check(lib.d4gs_raster_fwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), _stream()),
+                    "d4gs_raster_fwd")
 
         def launch(cap, max_hint):
             m = max(cap, 1)
@@ -215,42 +284,46 @@ class RasterFn(torch.autograd.Function):
             isect = L.fill(L.Isect(), **st.isect)
             isect.n_isect, isect.max_tile_count = m, max_hint
             L.check(lib.d4gs_bin_sort(C.byref(dims), C.byref(pout), C.byref(isect), _stream()), "d4gs_bin_sort")
-            L.check(lib.d4gs_raster_fwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), _stream()),
-                    "d4gs_raster_fwd")
+            raster(cap, max_hint)
 
-        # The list sizes live on the device.  Read them back through pinned memory; when a previous call of the same
-        # shape left a guess, launch binning + rasterization FIRST (sized by the guess, checked on the device) and wait
-        # for the counts afterwards, so the GPU never idles on the host round trip (70 us per render on MI355X).
-        key = (dev.index, S, cfg.N, W, H)
-        host_n = _pinned_counts(dev)
-        host_n.copy_(st.proj_out["n_isect"], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        guess = _SIZE_GUESS.get(key) if cfg.optimistic_sizes else None
-        if guess is not None:
-            launch(*guess)
-        ev.synchronize()
-        n, max_tile = host_n.tolist()
-        if guess is None or n > guess[0] or (guess[1] > 0 and max_tile > guess[1]):
+        if st.binned:
+            raster(st.n_isect, st.max_tile)
+        else:
+            # The list sizes live on the device.  Read them back through pinned memory; when a previous call of the same
+            # shape left a guess, launch binning + rasterization FIRST (sized by the guess, checked on the device) and
+            # wait for the counts afterwards, so the GPU never idles on the host round trip (70 us per render).
+            key = _size_key(dev, S, cfg.N, W, H)
+            host_n = _pinned_counts(dev)
+            host_n.copy_(st.proj_out["n_isect"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            guess = _guess_get(key) if cfg.optimistic_sizes else None
             if guess is not None:
-                _SIZE_STATS["relaunched"] += 1
-            launch(n, max_tile)
-        _SIZE_STATS["calls"] += 1
-        _SIZE_GUESS[key] = (n + n // 4 + 4096, 2048 if 3 * max_tile <= 2 * 2048 else 16384 if 3 * max_tile <= 2 * 16384 else 0)
-        st.n_isect, st.max_tile = n, max_tile
-        ctx.st = st
-        return st.raster["render_colors"].view(S, H, W, cfg.NCH), st.raster["render_alphas"].unsqueeze(-1)
+                launch(*guess)
+            ev.synchronize()
+            n, max_tile = host_n.tolist()
+            if guess is None or n > guess[0] or (guess[1] > 0 and max_tile > guess[1]):
+                if guess is not None:
+                    _SIZE_STATS["relaunched"] += 1
+                launch(n, max_tile)
+            _SIZE_STATS["calls"] += 1
+            _guess_put(key, (n + n // 4 + 4096,
+                             2048 if 3 * max_tile <= 2 * 2048 else 16384 if 3 * max_tile <= 2 * 16384 else 0))
+            st.n_isect, st.max_tile, st.binned = n, max_tile, True
+            st.raster = rst
+        ctx.st, ctx.cfg, ctx.rst, ctx.ctab = st, cfg, rst, ctab
+        return rst["render_colors"].view(S, H, W, cfg.NCH), rst["render_alphas"].unsqueeze(-1)
 
     @staticmethod
     def backward(ctx, v_colors, v_alphas):
         st: State = ctx.st
-        cfg = st.cfg
-        dev = st.raster["render_colors"].device
+        cfg, rst = ctx.cfg, ctx.rst
+        dev = rst["render_colors"].device
         f32 = dict(dtype=torch.float32, device=dev)
         lib = L.lib()
         S, N = cfg.S, cfg.N
         if v_colors is None:
-            v_colors = torch.zeros_like(st.raster["render_colors"])
+            v_colors = torch.zeros_like(rst["render_colors"])
         v_colors = v_colors.to(torch.float32).contiguous()
         v_alphas = None if v_alphas is None else v_alphas.to(torch.float32).contiguous()
         g = dict(
@@ -260,14 +333,14 @@ class RasterFn(torch.autograd.Function):
             v_depths=torch.empty(S, N, **f32), v_opac_act=torch.empty(N, **f32), v_ctab=torch.empty(N, cfg.DP, **f32),
         )
         dims = cfg.dims()
-        _, pout = _proj_structs(st)
+        pout = L.fill(L.ProjOut(), **{**st.proj_out, "ctab": ctx.ctab})
         isect = L.fill(L.Isect(), **st.isect)
         isect.n_isect, isect.max_tile_count = st.n_isect, st.max_tile
-        ras = L.fill(L.Raster(), **st.raster)
+        ras = L.fill(L.Raster(), **rst)
         rg = L.fill(L.RasterGrads(), **g)
         L.check(lib.d4gs_raster_bwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), C.byref(rg), _stream()),
                 "d4gs_raster_bwd")
-        return None, g["v_means2d"], g["v_conics"], g["v_depths"], g["v_opac_act"], g["v_ctab"], None
+        return None, None, g["v_means2d"], g["v_conics"], g["v_depths"], g["v_opac_act"], g["v_ctab"], None
 
 
 class PointsFn(torch.autograd.Function):
@@ -330,6 +403,14 @@ def render_instances(cfg: RenderCfg, means, quats, scales, opacities, colors, mo
                      viewmat, Kmat, background):
     """Deform + project + bin + sort + composite all S sub-samples.
     -> render_colors [S,H,W,D'], render_alphas [S,H,W,1], means2d [S,N,2], radii int32 [S,N], state."""
+    drop0 = cfg.D == 0  # e.g. return_color=False with depth only (scene_model.py:221-225): carry one zero channel
+    if drop0:
+        colors = torch.zeros(cfg.N, 1, dtype=torch.float32, device=means.device)
+        background = None if background is None else torch.zeros(1, dtype=torch.float32, device=means.device)
+        cfg = replace(cfg, D=1, n_sigmoid=0, flags=cfg.flags & ~L.RAW_COLORS)
+        rc, ra, m2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors, motion_coefs, rots,
+                                                  transls, times, RTs, viewmat, Kmat, background)
+        return rc[..., 1:], ra, m2d, radii, st
     st = State(cfg)
     if cfg.N == 0:  # an empty scene (e.g. everything culled): the image is the background, nothing to launch
         _need_gpu(means)
@@ -348,5 +429,24 @@ def render_instances(cfg: RenderCfg, means, quats, scales, opacities, colors, mo
                 torch.zeros(S, 0, dtype=torch.int32, device=dev), st)
     means2d, conics, depths, opac_act, ctab, radii = ProjectFn.apply(
         st, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat, Kmat)
-    rc, ra = RasterFn.apply(st, means2d, conics, depths, opac_act, ctab, background)
-    return rc, ra, means2d, radii, st
+    chunks = channel_chunks(cfg.D)
+    if len(chunks) == 1 and chunks[0][2] == cfg.D:  # the common case: one kernel width, nothing to slice or pad
+        rc, ra = RasterFn.apply(st, cfg, means2d, conics, depths, opac_act, ctab, background)
+        return rc, ra, means2d, radii, st
+    # any other channel count: chunks of <= 16 channels composited from the SAME projection + sorted tile lists
+    # (gsplat renders wide feature vectors in `channel_chunk`-sized passes the same way); autograd sums the chunks'
+    # per-instance gradients.  Only the first chunk's alpha is differentiated (they are all the same numbers).
+    F = torch.nn.functional
+    outs, ra = [], None
+    for k, (c0, c1, Dk) in enumerate(chunks):
+        last = k == len(chunks) - 1
+        ck = replace(cfg, D=Dk, depth_mode=cfg.depth_mode if last else L.DEPTH_NONE, grad_arena=None)
+        tab = F.pad(ctab[:, c0:c1], (0, ck.DP - (c1 - c0)))
+        bgk = None if background is None else F.pad(background.to(torch.float32).reshape(-1)[c0:c1], (0, Dk - (c1 - c0)))
+        rck, rak = RasterFn.apply(st, ck, means2d, conics, depths, opac_act, tab, bgk)
+        if ra is None:
+            ra = rak
+        outs.append(rck[..., :c1 - c0])
+        if last and cfg.depth_mode != L.DEPTH_NONE:
+            outs.append(rck[..., Dk:Dk + 1])
+    return torch.cat(outs, -1), ra, means2d, radii, st

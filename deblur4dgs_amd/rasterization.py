@@ -14,20 +14,6 @@ from . import _lib as L
 from .engine import RenderCfg, render_instances
 
 _MODES = {"RGB": L.DEPTH_NONE, "RGB+ED": L.DEPTH_ED, "RGB+D": L.DEPTH_D}
-SUPPORTED_D = (1, 2, 3, 4, 5, 8, 16)
-
-
-def _pad_channels(colors: torch.Tensor, backgrounds):
-    D = colors.shape[-1]
-    if D in SUPPORTED_D:
-        return colors, backgrounds, D
-    Dp = next((d for d in SUPPORTED_D if d >= D), None)
-    if Dp is None:
-        raise ValueError(f"colors with {D} channels: split into chunks of <= {SUPPORTED_D[-1]} channels")
-    colors = torch.nn.functional.pad(colors, (0, Dp - D))
-    if backgrounds is not None:
-        backgrounds = torch.nn.functional.pad(backgrounds, (0, Dp - D))
-    return colors, backgrounds, D
 
 
 def rasterization(
@@ -66,15 +52,13 @@ def rasterization(
     N = means.shape[0]
     assert quats.shape == (N, 4) and scales.shape == (N, 3) and opacities.shape == (N,) and colors.shape[0] == N
     bg = None if backgrounds is None else backgrounds[0]
-    colors_p, bg_p, D = _pad_channels(colors, bg)
-    cfg = RenderCfg(N=N, G=0, K=0, T=0, S=1, D=colors_p.shape[-1], width=width, height=height,
+    # any channel count: the engine composites it in chunks of <= 16 channels over one projection / one set of sorted
+    # tile lists (engine.channel_chunks), like gsplat's `channel_chunk`
+    cfg = RenderCfg(N=N, G=0, K=0, T=0, S=1, D=colors.shape[-1], width=width, height=height,
                     depth_mode=_MODES[render_mode], flags=0, near_plane=near_plane, far_plane=far_plane, eps2d=eps2d,
                     radius_clip=radius_clip, exact_cull=exact_cull)
-    rc, ra, means2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors_p, None, None, None,
-                                                  None, None, viewmats[0], Ks[0], bg_p)
-    if colors_p.shape[-1] != D:  # drop the padding channels (keep the depth channel if any)
-        keep = list(range(D)) + ([colors_p.shape[-1]] if cfg.depth_mode != L.DEPTH_NONE else [])
-        rc = rc[..., keep]
+    rc, ra, means2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors, None, None, None,
+                                                  None, None, viewmats[0], Ks[0], bg)
     tw, th = cfg.tiles
     info = {
         "means2d": means2d,

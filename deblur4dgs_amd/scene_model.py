@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .engine import track_points
-from .exposure import reference_policy, render_exposure
+from .exposure import render_exposure
 from .move_model import MoveModel
 
 BLUR_NUM_CAMERAS = 11  # scene_model.py:248
@@ -274,26 +274,17 @@ class SceneModel(nn.Module):
                     coefs = None
             N = P["means"].shape[0]
 
-        Dch = colors_override.shape[-1]
-        pad_to = next((d for d in (1, 2, 3, 4, 5, 8, 16) if d >= max(Dch, 1)), None)
-        assert pad_to is not None, f"{Dch} colour channels: at most 16 supported per render"
-        if pad_to != Dch:
-            colors_override = F.pad(colors_override, (0, pad_to - Dch))
-            bg_color = F.pad(bg_color, (0, pad_to - Dch))
+        # Any channel count (B target frames -> 3 + mask + 3B + depth): the engine composites wide colour vectors in
+        # chunks of <= 16 channels over one projection / one set of sorted tile lists and returns exactly these
+        # channels, so the reference's channel-index blend policy (3 <- max, 16 <- min, scene_model.py:392-393)
+        # is evaluated on the reference's own layout.
         res = render_exposure(
             P["means"], P["quats"], P["scales"], P["opacities"], colors_override, n_sigmoid, coefs,
             self.motion_bases.params["rots"] if G > 0 else None, self.motion_bases.params["transls"] if G > 0 else None,
             times_s if G > 0 else None, RTs_s, w2cs[0], Ks[0], W, H, background=bg_color[0], return_depth=return_depth,
             policy=None, blend=True)
-        keep = list(range(Dch)) + ([pad_to] if return_depth else [])
         blended = res["blended"][None]  # [1,H,W,D']
         renders = res["renders"]
-        if pad_to != Dch:
-            blended, renders = blended[..., keep], renders[..., keep]
-            # the reference's channel-index policy (3 <- max, 16 <- min) is evaluated on the UNPADDED layout
-            pol_ref = reference_policy(len(keep))
-            pol_pad = reference_policy(res["renders"].shape[-1])
-            assert [pol_pad[k] for k in keep] == pol_ref, "channel padding would move a max/min-policy channel"
 
         # side channels for densification (scene_model.py:456-461; consumed at trainer.py:967-989)
         m2d = res["means2d"]

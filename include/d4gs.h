@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D4GS_VERSION 100
+#define D4GS_VERSION 200
 #define D4GS_TILE 16
 #define D4GS_GEOM_STRIDE 8 /* floats per instance record: x, y, opacity, depth, conic a, b, c, pad */
 
@@ -239,6 +239,10 @@ int d4gs_camera_path_bwd(const float *jac, const float *dtimes, const float *del
  * -> enc [66] = [x, sin(x f), cos(x f)]_{f=1,2,4,8,16}, x = SE3_to_se3([R|T]). */
 int d4gs_pose_encode(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc /* [66] */,
                      void *stream);
+/* Its input gradient (test-time pose refinement differentiates the render w.r.t. w2c, which also feeds the
+ * MoveModel: flow3d/validator.py:442-448 -> flow3d/scene_model.py:249-256): v_enc [66] -> v_R [3,3] dense, v_T [3]. */
+int d4gs_pose_encode_bwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const float *v_enc,
+                         float *v_R /* [9] */, float *v_T /* [3] */, void *stream);
 
 /* The whole MoveModel (move_model.py:66-166) for one pose, one call each way: d4gs_pose_encode -> the 9-layer MLP
  * (66 -> 64 x4 LeakyReLU(0.01) -> 64, heads 64 -> 64 -> 6; ~30 GEMV launches per render in eager PyTorch) ->
@@ -265,6 +269,7 @@ typedef struct {
   float *v_b[9];
   float *v_time_params; /* [n_time_params] */
   float *v_delta;       /* [12] scratch */
+  float *v_enc;         /* [66] gradient of the pose encoding (input of d4gs_pose_encode_bwd), or NULL to skip */
 } D4gsMoveModelGrads;
 int d4gs_move_model_fwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const D4gsMoveModelParams *p,
                         int32_t S, int32_t index, float t, int32_t stage_first, const D4gsMoveModelOut *out, void *stream);

@@ -5,9 +5,13 @@ import torch
 
 from deblur4dgs_amd.synth import make_scene
 from oracle import scene as oscene
-from tests.util import frac_bad, rel_err
+from tests.util import check, frac_bad, rel_err
 
 pytestmark = pytest.mark.gpu
+# north_star's 1e-4 relative for images and every gradient (measured: profiles/r02_parity_table.md, typically 1e-5);
+# FLIPS = fraction of elements that may miss it because one alpha / T decision falls the other way in fp32
+GTOL, GFLIPS = 1e-4, 2e-3
+STOL = 1e-4                  # shared leaves (bases, times, camera deltas, viewmat): sums over all Gaussians, no allowance
 
 
 def _split(sc, dtype):
@@ -68,9 +72,10 @@ def test_exposure_forward_backward(N, G, K, S, W, H, mask, depth):
     res = render_exposure(P["means"], P["quats"], P["scales"], P["opacities"], colors_in, 3, coefs, rots, transls, tms,
                           rts, vm, sc["K"].float().to(dev), W, H, background=bgc, return_depth=depth)
     torch.cuda.synchronize()
-    assert frac_bad(res["renders"].cpu(), raw_stack, 1e-4) < 2e-3, rel_err(res["renders"].cpu(), raw_stack)
-    assert frac_bad(res["blended"].cpu(), blended_ref, 1e-4) < 2e-3
-    assert frac_bad(res["acc"].cpu(), out["acc"][0, ..., 0], 1e-4) < 2e-3
+    case = f"fused N={N} G={G} K={K} S={S} {W}x{H} mask={mask} depth={depth}"
+    check(case, "renders", res["renders"].cpu(), raw_stack, 1e-4, GFLIPS)
+    check(case, "blended", res["blended"].cpu(), blended_ref, 1e-4, GFLIPS)
+    check(case, "acc", res["acc"].cpu(), out["acc"][0, ..., 0], 1e-4, GFLIPS)
     loss = (res["blended"] * w_b.float().to(dev)).sum() + (res["acc"] * w_a[..., 0].float().to(dev)).sum() + \
         (res["renders"] * w_r.float().to(dev)).sum()
     loss.backward()
@@ -80,19 +85,20 @@ def test_exposure_forward_backward(N, G, K, S, W, H, mask, depth):
         return torch.cat([p[k].grad for p in (fg, bg) if p is not None], 0)
 
     for k in ("means", "quats", "scales", "colors", "opacities"):
-        assert frac_bad(P[k].grad.cpu(), ref_cat(k), 1e-3) < 3e-3, (k, rel_err(P[k].grad.cpu(), ref_cat(k)))
-    assert frac_bad(coefs.grad.cpu(), fg["motion_coefs"].grad, 1e-3) < 3e-3, rel_err(coefs.grad.cpu(), fg["motion_coefs"].grad)
-    assert rel_err(rots.grad.cpu(), bases["rots"].grad) < 2e-3, rel_err(rots.grad.cpu(), bases["rots"].grad)
-    assert rel_err(transls.grad.cpu(), bases["transls"].grad) < 2e-3
-    assert rel_err(tms.grad.cpu(), times.grad) < 2e-3, (tms.grad.cpu(), times.grad)
-    assert rel_err(rts.grad.cpu(), RTs.grad) < 2e-3
-    assert rel_err(vm.grad.cpu()[:3], w2c.grad[:3]) < 2e-3
+        check(case, k, P[k].grad.cpu(), ref_cat(k), GTOL, GFLIPS)
+    check(case, "motion_coefs", coefs.grad.cpu(), fg["motion_coefs"].grad, GTOL, GFLIPS)
+    # shared leaves: every element is a sum over all Gaussians (no isolated elements -> no flip allowance)
+    check(case, "rots", rots.grad.cpu(), bases["rots"].grad, STOL)
+    check(case, "transls", transls.grad.cpu(), bases["transls"].grad, STOL)
+    check(case, "times", tms.grad.cpu(), times.grad, STOL)
+    check(case, "RTs", rts.grad.cpu(), RTs.grad, STOL)
+    check(case, "viewmat", vm.grad.cpu()[:3], w2c.grad[:3], STOL)
 
 
 def test_track_points_match_oracle():
     """a11 (scene_model.py:258-289): positions at B target times in B target cameras, forward + all gradients."""
     from deblur4dgs_amd.engine import track_points
-    from deblur4dgs_amd.move_model import se3_to_SE3
+    from oracle.camera import se3_to_SE3
     from oracle import deform
 
     dev = torch.device("cuda:0")
@@ -114,11 +120,11 @@ def test_track_points_match_oracle():
     assert out.shape == (N, B, 3)
     (out * wgt.float().to(dev)).sum().backward()
     torch.cuda.synchronize()
-    assert rel_err(out.cpu(), ref) < 1e-5
-    assert rel_err(means.grad.cpu(), torch.cat([fg["means"].grad, bg["means"].grad], 0)) < 1e-4
-    assert rel_err(coefs.grad.cpu(), fg["motion_coefs"].grad) < 1e-4
-    assert rel_err(rots.grad.cpu(), bases["rots"].grad) < 1e-4
-    assert rel_err(transls.grad.cpu(), bases["transls"].grad) < 1e-4
+    check("a11 track points", "points", out.cpu(), ref, 1e-5)
+    check("a11 track points", "means", means.grad.cpu(), torch.cat([fg["means"].grad, bg["means"].grad], 0), 1e-4)
+    check("a11 track points", "motion_coefs", coefs.grad.cpu(), fg["motion_coefs"].grad, 1e-4)
+    check("a11 track points", "rots", rots.grad.cpu(), bases["rots"].grad, 1e-4)
+    check("a11 track points", "transls", transls.grad.cpu(), bases["transls"].grad, 1e-4)
 
 
 def test_grad_arena_receives_the_leaf_gradients_without_copies():

@@ -1,21 +1,33 @@
-"""BASELINE.json's full size (cfg2: 300 k Gaussians, 6 bases, 288x512, S = 8) is far beyond what the CPU oracle
-finishes in seconds, so at that size the HIP path is checked through size-independent properties:
-sortedness of every tile list, determinism, linearity of the image in (colours, background), exactness of the colour
-gradient via that linearity, permutation invariance, and 'sub-samples rendered in two calls == one call'."""
+"""BASELINE.json's full-size configurations - cfg2 (300 k Gaussians, 6 bases, 288x512, S = 8), cfg3 (the same at
+720x1280: 80x45 tiles, ~9 M intersections per sub-sample) and cfg5 (1 M Gaussians, 12 bases, 720x1280, S = 16) - are
+far beyond what the torch oracle finishes in seconds, so at those sizes the HIP path is checked through
+size-independent properties: sortedness + completeness of every tile list, determinism, linearity of the image in
+(colours, background), exactness of the colour gradient via that linearity, permutation invariance, and 'sub-samples
+rendered in two calls == one call'; plus one whole sub-sample of cfg2 and of cfg3 against the scalar-C fp64 oracle
+(image and every rasterizer-stage gradient).  Scenes and seeds are bench.py's."""
 import pytest
 import torch
 
 from deblur4dgs_amd.synth import make_scene
 
 pytestmark = pytest.mark.gpu
-N, G, K, S, W, H = 300_000, 300_000, 6, 8, 512, 288
+CONFIGS = {  # name: (N, G, K, S, W, H, seed)   == bench.py CONFIGS / SEEDS
+    "cfg2": (300_000, 300_000, 6, 8, 512, 288, 1001),
+    "cfg3": (300_000, 300_000, 6, 8, 1280, 720, 1002),
+    "cfg5": (1_000_000, 1_000_000, 12, 16, 1280, 720, 1004),
+}
 
 
-@pytest.fixture(scope="module")
-def scene():
+@pytest.fixture(scope="module", params=list(CONFIGS))
+def scene(request):
     dev = torch.device("cuda:0")
-    sc = make_scene(N, G, K, S, W, H, seed=1001)
-    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
+    N, G, K, S, W, H, seed = CONFIGS[request.param]
+    sc = make_scene(N, G, K, S, W, H, seed=seed)
+    out = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
+    out["name"] = request.param
+    yield out
+    del out
+    torch.cuda.empty_cache()
 
 
 def _render(sc, colors=None, bg=None, sel=None, perm=None, **kw):
@@ -31,11 +43,12 @@ def _render(sc, colors=None, bg=None, sel=None, perm=None, **kw):
         times, RTs = times[sel], RTs[sel]
     bg = torch.ones(3, device=sc["means"].device) if bg is None else bg
     return render_exposure(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], kw.pop("n_sigmoid", 3),
-                           P["motion_coefs"], sc["rots"], sc["transls"], times, RTs, sc["viewmat"], sc["K"], W, H,
+                           P["motion_coefs"], sc["rots"], sc["transls"], times, RTs, sc["viewmat"], sc["K"], sc["W"], sc["H"],
                            background=bg, return_depth=True, **kw)
 
 
 def test_every_tile_list_is_depth_sorted_and_complete(scene):
+    N, S = scene["N"], scene["S"]
     res = _render(scene)
     st = res["state"]
     torch.cuda.synchronize()
@@ -63,6 +76,7 @@ def test_determinism_and_exact_cull_at_full_size(scene):
 
 
 def test_image_is_linear_in_colours_and_background(scene):
+    N = scene["N"]
     dev = scene["means"].device
     g = torch.Generator(device="cpu").manual_seed(0)
     c1 = torch.rand(N, 3, generator=g).to(dev)
@@ -76,6 +90,7 @@ def test_image_is_linear_in_colours_and_background(scene):
 
 
 def test_colour_gradient_is_exact_by_linearity(scene):
+    N, W, H = scene["N"], scene["W"], scene["H"]
     dev = scene["means"].device
     g = torch.Generator(device="cpu").manual_seed(1)
     c = torch.rand(N, 3, generator=g).to(dev).requires_grad_()
@@ -92,29 +107,39 @@ def test_colour_gradient_is_exact_by_linearity(scene):
 
 
 def test_permuting_gaussians_leaves_the_image_unchanged(scene):
-    perm = torch.randperm(N, generator=torch.Generator().manual_seed(3)).to(scene["means"].device)
+    perm = torch.randperm(scene["N"], generator=torch.Generator().manual_seed(3)).to(scene["means"].device)
     a = _render(scene)["blended"]
     b = _render(scene, perm=perm)["blended"]
     torch.cuda.synchronize()
     # compositing order is by depth, so the image cannot depend on storage order - except where two splats of one
     # tile have bit-equal fp32 depths (a few thousand pairs among 2.4 M instances), which are ordered by index
     diff = (a - b).abs()
-    assert (diff > 1e-5 * a.abs().max()).float().mean() < 1e-3, diff.max()
+    # pairs with bit-equal depths grow like N^2: cfg2/cfg3 (2.4 M instances) touch < 1e-3 of the pixel values,
+    # cfg5 (16 M instances) 1.5e-3
+    lim = 1e-3 if scene["N"] <= 300_000 else 4e-3
+    assert (diff > 1e-5 * a.abs().max()).float().mean() < lim, diff.max()
     assert diff.max() < 0.05 * a.abs().max()
 
 
 def test_subsamples_in_two_calls_equal_one_call(scene):
+    S = scene["S"]
     full = _render(scene, blend=False)["renders"]
-    lo = _render(scene, sel=slice(0, 4), blend=False)["renders"]
-    hi = _render(scene, sel=slice(4, 8), blend=False)["renders"]
+    lo = _render(scene, sel=slice(0, S // 2), blend=False)["renders"]
+    hi = _render(scene, sel=slice(S // 2, S), blend=False)["renders"]
     torch.cuda.synchronize()
     assert torch.equal(full, torch.cat([lo, hi], 0))  # sub-samples are independent (the sharding premise)
 
 
 def test_full_size_subsample_matches_scalar_c_oracle(scene):
-    """One exposure sub-sample of cfg2 (300 k Gaussians, 288x512) against the scalar C restatement in fp64 - the only
-    oracle fast enough at this size (a few seconds): images and all per-Gaussian gradients of the rasterizer stage."""
+    """One exposure sub-sample of cfg2 (300 k Gaussians, 288x512) and of cfg3 (720x1280) against the scalar C
+    restatement in fp64 - the only oracle fast enough at this size: images and all per-Gaussian gradients of the
+    rasterizer stage.  (cfg5's single sub-sample is the same code path as cfg3's with 3.3x the splats: properties only.)"""
     import numpy as np
+
+    if scene["name"] == "cfg5":
+        pytest.skip("cfg5: property suite only (the scalar-C oracle needs minutes per sub-sample at 1 M x 720p)")
+    S, W, H = scene["S"], scene["W"], scene["H"]
+    case = f"{scene['name']} sub-sample vs scalar-C fp64"
 
     from deblur4dgs_amd.rasterization import rasterization
     from oracle import cref, deform
@@ -142,9 +167,13 @@ def test_full_size_subsample_matches_scalar_c_oracle(scene):
                                  render_mode="RGB+ED")
     ((rc[0] * wc.float().to(dev)).sum() + (ra[0] * wa.float().to(dev)).sum()).backward()
     torch.cuda.synchronize()
-    assert abs(info["n_isect"] - ctx["n_isect"]) >= 0  # (exact cull shortens our lists; images must still agree)
-    assert frac_bad(rc[0].cpu(), out, 1e-4) < 2e-3, rel_err(rc[0].cpu(), out)
-    assert frac_bad(ra[0].cpu(), al, 1e-4) < 2e-3
-    for name, key in (("means", "means"), ("quats", "quats"), ("scales", "scales"), ("opac", "opac"), ("colors", "colors")):
-        got = t[name].grad.cpu()
-        assert frac_bad(got, ref[key], 1e-3) < 3e-3, (name, rel_err(got, ref[key]))
+    # exact culling only removes pairs no pixel of which passes the alpha test: never more lists than gsplat's own
+    assert 0 < info["n_isect"] <= ctx["n_isect"]
+    from tests.util import check
+
+    # 1e-4 relative for the image and every gradient; at most 1e-4 of the elements may miss it (measured 2e-5: a few
+    # dozen of 300 k Gaussians sit on a discrete alpha / T decision that falls the other way in fp32)
+    check(case, "render_colors", rc[0].cpu(), out, 1e-4, 1e-4)
+    check(case, "render_alphas", ra[0].cpu(), al, 1e-4, 1e-4)
+    for name in ("means", "quats", "scales", "opac", "colors"):
+        check(case, name, t[name].grad.cpu(), ref[name], 1e-4, 1e-4)

@@ -9,10 +9,17 @@ import pytest
 import torch
 
 from oracle import raster
-from tests.util import frac_bad, rel_err, static_inputs
+from tests.util import check, frac_bad, rel_err, static_inputs
 
 pytestmark = pytest.mark.gpu
+# north_star: "within 1e-4 relative" - asserted as |a-b| <= 1e-4 max|ref| per tensor against the fp64 oracle, for images
+# AND gradients.  Measured (profiles/r02_parity_table.md): typical 1e-6..2e-5; what exceeds 1e-4 is a handful of
+# elements where a discrete decision (alpha >= 1/255, T <= 1e-4, ceil(radius)) falls the other way in fp32.
 TOL = 1e-4
+GTOL = 1e-4
+FLIPS = 2e-3    # fraction of elements allowed to miss it (~2 Gaussians of 1000; measured <= 8e-4 at these sizes)
+GFLIPS = FLIPS
+VTOL = 1e-4     # viewmat gradient: a sum over all Gaussians (measured <= 2e-5); no flip allowance
 
 
 def _run_gpu(inp, W, H, mode, bg, requires_grad=False, exact_cull=True):
@@ -51,8 +58,9 @@ def test_forward_matches_oracle(mode, D, N, W, H):
     assert (info["radii"][0].cpu()[both] != ref_info["radii"][both]).float().mean() < 1e-3
     assert abs(info["n_isect"] - ref_info["n_isect"]) <= 0.002 * ref_info["n_isect"] + 2
     # images
-    assert frac_bad(rc[0].cpu(), ref_c, TOL) < 2e-3, rel_err(rc[0].cpu(), ref_c)
-    assert frac_bad(ra[0].cpu(), ref_a, TOL) < 2e-3, rel_err(ra[0].cpu(), ref_a)
+    case = f"S1 fwd {mode} D={D} N={N} {W}x{H}"
+    check(case, "render_colors", rc[0].cpu(), ref_c, TOL, FLIPS)
+    check(case, "render_alphas", ra[0].cpu(), ref_a, TOL, FLIPS)
 
 
 def test_sorted_ids_match_oracle_order():
@@ -65,8 +73,10 @@ def test_sorted_ids_match_oracle_order():
     torch.cuda.synchronize()
     a = info["flatten_ids"].cpu().long()
     b = ref_info["flatten_ids"]
-    if a.shape == b.shape:
-        assert (a != b).float().mean() < 5e-3  # equal up to depth ties / 1-ulp depth differences
+    # fp32 oracle + gsplat's own tile lists: the same keys, so the same number of intersections and - up to splats whose
+    # fp32 depth or radius differs in the last ulp between the two implementations - the same order
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert (a != b).float().mean() < 5e-3
     offs = info["isect_offsets"].flatten().cpu().long()
     assert (offs[1:] >= offs[:-1]).all()
 
@@ -109,13 +119,12 @@ def test_backward_matches_oracle(mode, D, N, W, H):
     dev = rc.device
     ((rc[0] * w_c.to(dev).float()).sum() + (ra[0] * w_a.to(dev).float()).sum()).backward()
     torch.cuda.synchronize()
+    case = f"S1 bwd {mode} D={D} N={N} {W}x{H}"
     # the means2d.grad contract (trainer.py:975)
-    assert frac_bad(info["means2d"].grad[0].cpu(), ref_info["means2d"].grad, 1e-3) < 2e-3
+    check(case, "means2d.grad", info["means2d"].grad[0].cpu(), ref_info["means2d"].grad, GTOL, GFLIPS)
     for name in ("means", "quats", "scales", "opac", "colors"):
-        got, ref = tg[name].grad.cpu(), t[name].grad
-        assert frac_bad(got, ref, 1e-3) < 3e-3, (name, rel_err(got, ref))
-    got, ref = tg["V"].grad.cpu()[:3], t["V"].grad[:3]
-    assert rel_err(got, ref) < 2e-3, ("viewmat", rel_err(got, ref))
+        check(case, name, tg[name].grad.cpu(), t[name].grad, GTOL, GFLIPS)
+    check(case, "viewmat", tg["V"].grad.cpu()[:3], t["V"].grad[:3], VTOL, 0.0)
 
 
 def test_backward_is_deterministic():
@@ -238,9 +247,10 @@ def test_big_splats_and_cull_parameters(scale_mul, radius_clip, near, far):
     (rc.sum() + ra.sum()).backward()
     torch.cuda.synchronize()
     assert ((info["radii"][0].cpu() > 0) != (ref_info["radii"] > 0)).float().mean() < 5e-3
-    assert frac_bad(rc[0].cpu(), ref_c, 1e-4) < 3e-3, rel_err(rc[0].cpu(), ref_c)
+    case = f"S1 big splats x{scale_mul} clip={radius_clip} near={near} far={far}"
+    check(case, "render_colors", rc[0].cpu(), ref_c, TOL, FLIPS)
     for name in ("means", "scales", "opac", "colors"):
-        assert frac_bad(g[name].grad.cpu(), t[name].grad, 2e-3) < 5e-3, (name, rel_err(g[name].grad.cpu(), t[name].grad))
+        check(case, name, g[name].grad.cpu(), t[name].grad, GTOL, GFLIPS)
 
 
 def test_empty_scene_renders_the_background():
@@ -294,9 +304,10 @@ def test_channel_counts_padding_and_depth_modes(mode, D):
     assert rc.shape == (1, H, W, D + (mode != "RGB"))
     ((rc[0] * wc.float().to(rc.device)).sum() + ra.sum()).backward()
     torch.cuda.synchronize()
-    assert frac_bad(rc[0].cpu(), ref_c, 1e-4) < 2e-3, rel_err(rc[0].cpu(), ref_c)
+    case = f"S1 channels {mode} D={D}"
+    check(case, "render_colors", rc[0].cpu(), ref_c, TOL, FLIPS)
     for name in ("means", "opac", "colors"):
-        assert frac_bad(tg[name].grad.cpu(), t[name].grad, 1e-3) < 3e-3, (name, rel_err(tg[name].grad.cpu(), t[name].grad))
+        check(case, name, tg[name].grad.cpu(), t[name].grad, GTOL, GFLIPS)
 
 
 def test_optimistic_list_sizes_relaunch_when_the_guess_is_too_small():
@@ -388,13 +399,22 @@ def test_seeded_random_sweep_forward_and_backward(i, mode, D, N, W, H, scale_mul
     dev = rc.device
     ((rc[0] * w_c.to(dev).float()).sum() + (ra[0] * w_a.to(dev).float()).sum()).backward()
     torch.cuda.synchronize()
-    assert frac_bad(rc[0].cpu(), ref_c, TOL) < 4e-3, rel_err(rc[0].cpu(), ref_c)
-    assert frac_bad(ra[0].cpu(), ref_a, TOL) < 4e-3, rel_err(ra[0].cpu(), ref_a)
+    case = f"S1 sweep {i}: {mode} D={D} N={N} {W}x{H} x{scale_mul}"
+    check(case, "render_colors", rc[0].cpu(), ref_c, TOL, FLIPS)
+    check(case, "render_alphas", ra[0].cpu(), ref_a, TOL, FLIPS)
+    # Conditioning reference: the SAME oracle evaluated in fp32.  For sub-pixel splats the 2-D covariance is dominated
+    # by the eps2d = 0.3 blur and the gradient w.r.t. quats / scales is a small difference of large terms: any fp32
+    # implementation (the reference's CUDA path included) differs from fp64 by more than 1e-4 there (cases 2 and 11:
+    # 2e-4 / 5e-3 for the fp32 oracle itself).  The HIP path must be within 1e-4, or as accurate as fp32 allows.
+    t32 = {k: v.detach().float().requires_grad_(k != "K") for k, v in inp.items()}
+    c32, a32, _ = raster.rasterization(t32["means"], t32["quats"], t32["scales"], t32["opac"], t32["colors"], t32["V"],
+                                       t32["K"], W, H, background=None if bg is None else bg.float(), render_mode=mode)
+    ((c32 * w_c.float()).sum() + (a32 * w_a.float()).sum()).backward()
     for name in ("means", "quats", "scales", "opac", "colors"):
         got, ref = tg[name].grad.cpu(), t[name].grad
         assert torch.isfinite(got).all()
-        # a handful of Gaussians: one alpha >= 1/255 decision taken differently in fp32 moves a whole row by ~0.5 %
-        assert frac_bad(got, ref, 2e-3) < 1e-2 or rel_err(got, ref) < 1e-2, (name, rel_err(got, ref))
+        cond = rel_err(t32[name].grad, ref)
+        check(case, name, got, ref, max(GTOL, 2.0 * cond), GFLIPS)
 
 
 @pytest.mark.parametrize("D", [3, 16])
