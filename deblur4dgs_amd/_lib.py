@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libd4gs.so")
+LIB_PATH = os.environ.get("D4GS_LIB_PATH") or os.path.join(HERE, "libd4gs.so")  # override: A/B builds (scripts/)
 
 F = C.c_void_p  # device pointers travel as void*
 

@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef D4GS_ABL
+#define D4GS_ABL 0  // scripts/ablate.sh builds cost-attribution variants: 1 no wave reduction, 2 no gradient math,
+#endif              // 3 neither, 4 list walk only (results are garbage; timing only)
 template <int D, bool DEPTH>
 __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
 #pragma clang fp contract(off)
@@ -381,6 +384,10 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         m &= m - 1;
         const int cur = bh - j;
         const float4 g0 = sg0[j], g1 = sg1[j];
+#if D4GS_ABL == 4
+        T += g0.x + g1.x + (float)cur;
+        continue;
+#endif
         const float dx = g0.x - pxf, dy = g0.y - pyf;
         const float sig2 = splat_sigma2(g1, dx, dy);
         const float ov = g0.z * __builtin_amdgcn_exp2f(-sig2);
@@ -388,6 +395,20 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         const bool valid = (cur <= last) && (sig2 >= 0.f) && (alpha >= (1.f / 255.f));
         if (!__any(valid)) continue;
         const float am = valid ? alpha : 0.f;
+#if D4GS_ABL == 2 || D4GS_ABL == 3
+        {
+          float arow[RV];
+          T += am;
+#pragma unroll
+          for (int r = 0; r < RV; r++) arow[r] = am + (float)r;
+#if D4GS_ABL == 2
+          wave_sum_store(arow, sgrad, (wvs * NB + j) * RP, lane);
+#else
+          if (lane == 0) sgrad[(wvs * NB + j) * RP] = arow[0] + arow[RV - 1];
+#endif
+          continue;
+        }
+#endif
         const float ra = __builtin_amdgcn_rcpf(1.f - am);
         T *= ra;
         const float fac = am * T;
@@ -420,7 +441,16 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         row[3] = vsx * dy;
         row[4] = vsy * dy;
         row[5] = vs;
+#if D4GS_ABL == 1
+        {
+          float acc = 0.f;
+#pragma unroll
+          for (int r = 0; r < RV; r++) acc += row[r];
+          if (valid) sgrad[(wvs * NB + j) * RP + (lane & 7)] = acc;
+        }
+#else
         wave_sum_store(row, sgrad, (wvs * NB + j) * RP, lane);
+#endif
         if constexpr (MC > 0) {
           if (++nh == 16) {
             flush(16);

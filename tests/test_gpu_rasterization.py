@@ -288,10 +288,13 @@ def test_single_gaussian_and_api_errors():
                       torch.eye(4)[None], K.cpu(), 40, 24)
 
 
-@pytest.mark.parametrize("mode,D", [("RGB+D", 3), ("RGB", 1), ("RGB+ED", 2), ("RGB+ED", 6), ("RGB", 7), ("RGB+ED", 8)])
+@pytest.mark.parametrize("mode,D", [("RGB+D", 3), ("RGB", 1), ("RGB+ED", 2), ("RGB+ED", 6), ("RGB", 7), ("RGB+ED", 8),
+                                    ("RGB+ED", 17), ("RGB", 20), ("RGB+ED", 32), ("RGB+D", 33)])
 def test_channel_counts_padding_and_depth_modes(mode, D):
-    """Every channel instantiation (1,2,3,4,5,8,16) incl. host-side padding of odd counts (6,7 -> 8), the un-normalised
-    depth mode RGB+D, and no background - forward and colour / opacity / means gradients."""
+    """Every channel instantiation (1,2,3,4,5,8,16), ragged counts padded to the next one (6,7 -> 8), wide colour
+    vectors composited in chunks of 16 over one projection / one set of tile lists (17, 20, 32, 33; gsplat's
+    channel_chunk), the un-normalised depth mode RGB+D, and no background - forward and colour / opacity / means
+    gradients."""
     W, H, N = 80, 56, 900
     inp = static_inputs(N, W, H, seed=400 + D, dtype=torch.float64, D=D)
     t = {k: v.clone().requires_grad_(k != "K") for k, v in inp.items()}

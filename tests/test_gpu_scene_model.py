@@ -7,21 +7,21 @@ import torch
 from deblur4dgs_amd.synth import make_scene
 from oracle import camera as ocam
 from oracle import scene as oscene
-from tests.util import frac_bad, record, rel_err
+from tests.util import check, frac_bad, record, rel_err
 
 pytestmark = pytest.mark.gpu
 GRAD_FLIP_FRAC = 2e-3   # elements allowed to miss 1e-4 (a discrete alpha / T decision taken differently in fp32)
 MM_TOL = 1e-4           # MoveModel grads (sums over all pixels and Gaussians): measured <= 2e-5
 
 
-def _build(N, G, K, W, H, seed, dev):
+def _build(N, G, K, W, H, seed, dev, has_bg=True):
     from deblur4dgs_amd.scene_model import GaussianParams, MotionBases, SceneModel
 
     sc = make_scene(N, G, K, 1, W, H, seed=seed, dtype=torch.float32, T=8)
     sc["scales"] = sc["scales"] + 1.3
     keys = ("means", "quats", "scales", "colors", "opacities")
     fg = GaussianParams(*[sc[k][:G].clone() for k in keys], motion_coefs=sc["motion_coefs"].clone())
-    bg = GaussianParams(*[sc[k][G:].clone() for k in keys])
+    bg = GaussianParams(*[sc[k][G:].clone() for k in keys]) if has_bg else None
     mb = MotionBases(sc["rots"].clone(), sc["transls"].clone())
     model = SceneModel(sc["K"][None].clone(), sc["viewmat"][None].clone(), fg, mb, bg).to(dev)
     torch.manual_seed(seed)
@@ -36,7 +36,7 @@ def _oracle(model, sc, t, W, H, mode, stage, return_depth, return_mask, target_t
     G = model.num_fg_gaussians
     dd = lambda x: x.detach().double().cpu().clone().requires_grad_()
     fg = {k: dd(v) for k, v in model.fg.params.items()}
-    bg = {k: dd(v) for k, v in model.bg.params.items()}
+    bg = {k: dd(v) for k, v in model.bg.params.items()} if model.bg is not None else None
     bases = {k: dd(v) for k, v in model.motion_bases.params.items()}
     sd = {k: v.detach().cpu().double().requires_grad_() for k, v in model.move_model.state_dict().items()}
     w2c = sc["viewmat"].double()
@@ -105,6 +105,48 @@ def test_render_matches_oracle(mode, stage, t, tracks):
     if mode == "blury":
         assert model.move_model.RT_head0[-1].bias.grad.abs().sum() > 0  # camera deltas are trained through v_RTs
         assert (model.move_model.time_params.grad.abs().sum() > 0) == (stage == "second")
+
+
+@pytest.mark.parametrize("has_bg,B,depth,mask", [(False, 4, True, False),   # trainer.py:506-517 without a background:
+                                                  #   3 + 12 track channels + depth = 16 -> depth sits on index 15 (mean)
+                                                  (True, 2, True, True), (True, 3, True, True),
+                                                  (True, 6, True, True),     # 3 + 1 + 18 + depth = 23 channels: 2 chunks
+                                                  (False, 7, False, False),  # 24 channels, no depth
+                                                  (True, 11, True, True)])   # 3 + 1 + 33 + 1 = 38 channels: 3 chunks
+def test_any_channel_layout_matches_the_reference_policy(has_bg, B, depth, mask):
+    """layouts the reference accepts but the 16-channel padding used to reject or mis-blend.  The engine
+    composites any channel count in chunks over one projection / one set of tile lists and the blend policy
+    (channel 3 <- max, 16 <- min; scene_model.py:392-393) is evaluated on the reference's own layout."""
+    dev = torch.device("cuda:0")
+    N, G, K, W, H = 700, 700 if not has_bg else 400, 3, 64, 48
+    model, sc = _build(N, G, K, W, H, 31 + B, dev, has_bg=has_bg)
+    tt = torch.linspace(0.5, 6.5, B)
+    from oracle.camera import se3_to_SE3
+
+    g = torch.Generator().manual_seed(B)
+    tw = torch.cat([se3_to_SE3(0.01 * torch.randn(B, 6, generator=g)), torch.tensor([0, 0, 0, 1.0]).expand(B, 1, 4)], 1)
+    ref, (fg, bg, bases, mm_sd), dT = _oracle(model, sc, 3.0, W, H, "blury", "second", depth, mask, tt.double(), tw.double())
+    out = model.render(3.0, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H), target_ts=tt.to(dev),
+                       target_w2cs=tw.to(dev), return_depth=depth, return_mask=mask, mode="blury", stage="second")
+    Dp = 3 + int(mask) + 3 * B + int(depth)
+    assert out["exposure_imgs"].shape == (11, 1, H, W, Dp) and out["tracks_3d"].shape == (1, H, W, B, 3)
+    case = f"S2 layout bg={has_bg} B={B} depth={depth} mask={mask} ({Dp} channels)"
+    names = ("img", "tracks_3d", "acc") + (("depth",) if depth else ()) + (("mask",) if mask else ())
+    for k in names:
+        check(case, k, out[k].cpu(), ref[k], 1e-4, GRAD_FLIP_FRAC)
+    check(case, "exposure_imgs", out["exposure_imgs"].cpu(), ref["exposure_imgs"], 1e-4, GRAD_FLIP_FRAC)
+    w = torch.randn(out["tracks_3d"].shape, generator=g)
+    wi = torch.randn(1, H, W, 3, generator=g)
+    ((out["tracks_3d"] * w.to(dev)).sum() + (out["img"] * wi.to(dev)).sum() + (out["depth"].sum() if depth else 0.0)).backward()
+    ((ref["tracks_3d"] * w.double()).sum() + (ref["img"] * wi.double()).sum() + (ref["depth"].sum() if depth else 0.0)).backward()
+    torch.cuda.synchronize()
+    for name, got_p, ref_p in (("fg.means", model.fg.params["means"], fg["means"]),
+                               ("fg.colors", model.fg.params["colors"], fg["colors"]),
+                               ("fg.opacities", model.fg.params["opacities"], fg["opacities"]),
+                               ("fg.motion_coefs", model.fg.params["motion_coefs"], fg["motion_coefs"]),
+                               ("rots", model.motion_bases.params["rots"], bases["rots"]),
+                               ("transls", model.motion_bases.params["transls"], bases["transls"])):
+        check(case, name, got_p.grad.cpu(), ref_p.grad, 1e-4, GRAD_FLIP_FRAC)
 
 
 def test_render_view_and_inference_mode():
