@@ -7,13 +7,17 @@ exposure blend -> loss = <blended, Wimg> + <acc, Wacc> -> gradients to every lea
 opacities, colours, motion coefficients, bases, times, camera deltas, viewmat).  Inputs are resident in HBM
 before the timed region.  value = Gaussians / t_frame (whole job); `instances_per_s` = N*S / t_frame.
 
-N GPUs (torchrun, one rank per GPU, RCCL):
-  --shard views (default): every rank renders its own full S-sub-sample frame (data parallel over camera views, the
-      unit a training step batches: flow3d/trainer.py:211-222 renders 3 independent groups per step), leaf gradients
-      all-reduced in one flat buffer.  Per-GPU work fixed -> "scaling": "weak"; value = world * N / t.
-  --shard exposure: BASELINE config 4 - the S sub-samples of the SAME frame are split over the ranks, the blended
-      image is an all-reduce (SUM, + MAX/MIN channels), leaf gradients are all-reduced.  Total work is fixed ->
-      "scaling": "strong" (latency-bound: one sub-sample is ~0.5 ms of GPU work against a 24 MB gradient all-reduce).
+Configs (`--config`): cfg1 / cfg2 (headline, default) / cfg3 / cfg5 = BASELINE.json's, `refdefault[720]` = the
+reference's own training shape (40 k dynamic + 100 k static Gaussians, 20 bases, 11 sub-samples, 17 channels:
+run_training_dynamic.py:118-120, scene_model.py:233-296).  `--scale-mul F` multiplies every Gaussian's extent by F
+(SURVEY 8d's distribution has sub-2-pixel splats; real scenes have larger footprints).
+
+N GPUs (torchrun, one rank per GPU, RCCL): the default is BASELINE config 4 - `--shard exposure`: the S sub-samples of
+the SAME frame are split over the ranks, the blended image is an all-reduce (SUM, + MAX/MIN channels), leaf gradients
+are all-reduced; total work is fixed -> "scaling": "strong", value = N / t, and the N = 1 value equals the single-GPU
+line.  The view-sharded (data-parallel) throughput - every rank renders its own full frame, "weak" scaling,
+value = world * N / t - is measured right after the timed region and reported as the secondary object
+`views_weak_scaling`.  `--shard views` makes it the primary line instead.
 """
 from __future__ import annotations
 
@@ -21,6 +25,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,18 +36,23 @@ sys.path.insert(0, ROOT)
 
 CONFIGS = {
     # name: (N, G, K, S, W, H)
+    "cfg1": (10_000, 0, 1, 1, 512, 288),
     "cfg2": (300_000, 300_000, 6, 8, 512, 288),
     "cfg3": (300_000, 300_000, 6, 8, 1280, 720),
     "cfg5": (1_000_000, 1_000_000, 12, 16, 1280, 720),
+    "refdefault": (140_000, 40_000, 20, 11, 512, 288),
+    "refdefault720": (140_000, 40_000, 20, 11, 1280, 720),
     "tiny": (20_000, 12_000, 4, 4, 256, 144),
 }
-SEEDS = {"cfg2": 1001, "cfg3": 1002, "cfg5": 1004, "tiny": 1099}
+SEEDS = {"cfg1": 1000, "cfg2": 1001, "cfg3": 1002, "cfg5": 1004, "refdefault": 1010, "refdefault720": 1011, "tiny": 1099}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F32_PEAK_TFLOPS = 157.3  # fp32 vector peak == fp32-input dense MFMA peak (MI355X_MICROARCH.md)
+N_CU, N_SIMD, N_XCD = 256, 1024, 8
 # ALGORITHMIC FP32 ops per (splat, pixel) of the reference composite (gsplat rasterize_to_pixels fwd / bwd at 4
 # channels), SURVEY.md section 8(d): ~30 forward, ~90 backward.  The HIP kernels execute fewer.
 FLOPS_PER_PAIR_BWD = 90.0
 FLOPS_PER_PAIR_FWD = 30.0
+FLOPS_INVALID_PAIR = 12.0  # what a pair that fails the alpha test needs at minimum: delta, sigma, exp, alpha, the test
 
 
 def parse():
@@ -51,11 +61,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=list(CONFIGS))
-    ap.add_argument("--shard", default="views", choices=["exposure", "views"])
-    ap.add_argument("--channels", type=int, default=3, choices=[3, 16],
+    ap.add_argument("--shard", default="exposure", choices=["exposure", "views"])
+    ap.add_argument("--channels", type=int, default=None, choices=[3, 16],
                     help="colour channels before depth: 3 = RGB+ED (headline), 16 = the reference's dynamic-training "
-                         "shape (rgb + mask + 4x3 track channels + depth = 17, scene_model.py:233-296)")
+                         "shape (rgb + mask + 4x3 track channels + depth = 17, scene_model.py:233-296; default of "
+                         "--config refdefault*)")
+    ap.add_argument("--scale-mul", type=float, default=1.0, help="multiply every Gaussian's extent (footprint sensitivity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="BASELINE.md section 3's whole plan (cfg1 x 20 iterations, cfg2 x 3, torch and scalar C); minutes")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL code path with world_size 1")
     return ap.parse_args()
@@ -65,57 +79,34 @@ def to_dev(sc, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
 
 
-def make_inputs(name, dev, seed_offset=0, channels=3):
+LEAVES = ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls", "times", "RTs", "viewmat")
+
+
+def scene_of(name, seed_offset=0, channels=3, scale_mul=1.0):
+    import math
+
     from deblur4dgs_amd.synth import make_scene
 
     N, G, K, S, W, H = CONFIGS[name]
-    sc = make_scene(N, G, K, S, W, H, seed=SEEDS[name] + seed_offset, D=channels)
+    sc = make_scene(N, G, K, S, W, H, seed=SEEDS[name] + seed_offset, D=channels,
+                    cam_jitter=0.0 if name == "cfg1" else 0.002)  # identity camera delta for cfg1
+    if scale_mul != 1.0:
+        sc["scales"] = sc["scales"] + math.log(scale_mul)
+    return sc
+
+
+def make_inputs(name, dev, seed_offset=0, channels=3, scale_mul=1.0):
+    N, G, K, S, W, H = CONFIGS[name]
+    sc = scene_of(name, seed_offset, channels, scale_mul)
     d = to_dev(sc, dev)
-    leaves = {k: d[k].clone().requires_grad_() for k in
-              ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls", "times", "RTs",
-               "viewmat")}
+    leaves = {k: d[k].clone().requires_grad_() for k in LEAVES if k in d and (G > 0 or k not in ("times",))}
     g = torch.Generator().manual_seed(7)
     wimg = torch.randn(H, W, channels + 1, generator=g).to(dev)
     wacc = torch.randn(H, W, generator=g).to(dev)
     return sc, d, leaves, wimg, wacc
 
 
-def cpu_baseline(name):
-    """The build's CPU restatement (oracle; the reference has NO CPU path - flow3d/scene_model.py:36,360) timed
-    on this box's host cores on a bounded sample: ONE exposure sub-sample (the middle one) of the same seeded scene,
-    forward + backward through oracle/raster_ref.c (scalar C, 1 core), deformation applied by oracle/deform.py."""
-    import numpy as np
-
-    from deblur4dgs_amd.synth import make_scene
-    from oracle import cref, deform
-
-    N, G, K, S, W, H = CONFIGS[name]
-    sc = make_scene(N, G, K, S, W, H, seed=SEEDS[name])
-    s = S // 2
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        fg = {k: sc[k] for k in ("means", "quats", "motion_coefs")}
-        m, q = deform.compute_poses_fg(sc["times"][s:s + 1], fg["means"], fg["quats"], fg["motion_coefs"], sc["rots"],
-                                       sc["transls"])
-        m = deform.camera_delta(m[:, 0], sc["RTs"][s])
-        q = q[:, 0]
-        scales, opac, cols = torch.exp(sc["scales"]), torch.sigmoid(sc["opacities"]), torch.sigmoid(sc["colors"])
-    out, al, ctx = cref.rasterization(m.numpy(), q.numpy(), scales.numpy(), opac.numpy(), cols.numpy(),
-                                      sc["viewmat"].numpy(), sc["K"].numpy(), W, H, background=np.ones(3, np.float32),
-                                      render_mode="RGB+ED", dtype=np.float32)
-    rng = np.random.default_rng(0)
-    cref.backward(ctx, rng.standard_normal(out.shape).astype(np.float32),
-                  rng.standard_normal(al.shape).astype(np.float32))
-    t_sub = time.perf_counter() - t0
-    return {
-        "value": N / (t_sub * S), "unit": "Gaussians/s", "cores": 1, "kind": "port",
-        "sample": f"1 of {S} exposure sub-samples of {name} ({N} Gaussians, {W}x{H}), fwd+bwd through the oracle "
-                  f"(torch deform + scalar C rasterizer, 1 thread) in {t_sub:.2f} s; value = N / (S * t_sub)",
-        "n_isect_sample": ctx["n_isect"],
-        "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
-    }
-
-
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -124,6 +115,143 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def _cpu_frame_scalar_c(sc, name, threads):
+    """One full blurry frame, forward + backward, through the scalar-C restatement (oracle/raster_ref.c) - the S
+    sub-samples in parallel threads (ctypes releases the GIL), deformation by the torch restatement.  -> seconds."""
+    import concurrent.futures as cf
+
+    import numpy as np
+
+    from oracle import cref, deform
+
+    N, G, K, S, W, H = CONFIGS[name]
+    D = sc["colors"].shape[-1]
+    rng = np.random.default_rng(0)
+    w_out = rng.standard_normal((H, W, D + 1)).astype(np.float32)
+    w_al = rng.standard_normal((H, W, 1)).astype(np.float32)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        scales, opac, cols = torch.exp(sc["scales"]), torch.sigmoid(sc["opacities"]), torch.sigmoid(sc["colors"])
+        quat_static = torch.nn.functional.normalize(sc["quats"], dim=-1)
+
+    def sub(s):
+        with torch.no_grad():
+            if G > 0:
+                fg = {k: sc[k][:G] for k in ("means", "quats")}
+                m, q = deform.compute_poses_fg(sc["times"][s:s + 1], fg["means"], fg["quats"], sc["motion_coefs"], sc["rots"],
+                                               sc["transls"])
+                m, q = m[:, 0], q[:, 0]
+                if G < N:
+                    m, q = torch.cat([m, sc["means"][G:]], 0), torch.cat([q, quat_static[G:]], 0)
+            else:
+                m, q = sc["means"], quat_static
+            m = deform.camera_delta(m, sc["RTs"][s])
+        out, al, ctx = cref.rasterization(m.numpy(), q.numpy(), scales.numpy(), opac.numpy(), cols.numpy(),
+                                          sc["viewmat"].numpy(), sc["K"].numpy(), W, H, background=np.ones(D, np.float32),
+                                          render_mode="RGB+ED", dtype=np.float32)
+        cref.backward(ctx, w_out, w_al)
+        return ctx["n_isect"]
+
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        n_isect = sum(ex.map(sub, range(S)))
+    return time.perf_counter() - t0, n_isect
+
+
+TORCH_CPU_THREADS = 16  # measured on the GPU box's 256-thread EPYC 9575F host: with set_num_threads(256) one cfg1 frame
+#                         of the torch restatement takes 205-831 s (thousands of tiny ops, thread oversubscription) against
+#                         ~3 s on 8-16 threads - so the torch leg pins 16 threads and says so
+
+
+def _cpu_frame_torch(sc, name):
+    """The same frame through the vectorised torch restatement (oracle/scene.py), fp32, TORCH_CPU_THREADS threads."""
+    from oracle import scene as oscene
+
+    torch.set_num_threads(min(TORCH_CPU_THREADS, os.cpu_count()))
+    N, G, K, S, W, H = CONFIGS[name]
+    keys = ("means", "quats", "scales", "colors", "opacities")
+    fg = bg = bases = None
+    if G > 0:
+        fg = {k: sc[k][:G].clone().requires_grad_() for k in keys}
+        fg["motion_coefs"] = sc["motion_coefs"].clone().requires_grad_()
+        bases = {k: sc[k].clone().requires_grad_() for k in ("rots", "transls")}
+    if G < N:
+        bg = {k: sc[k][G:].clone().requires_grad_() for k in keys}
+    t0 = time.perf_counter()
+    ref = oscene.render_exposure(fg, bg, bases, sc["times"], sc["RTs"], sc["viewmat"], sc["K"], (W, H), bg_color=1.0,
+                                 return_depth=True, single=(S == 1))
+    (ref["img"].sum() + ref["depth"].sum() + ref["acc"].sum()).backward()
+    return time.perf_counter() - t0
+
+
+def _stats(ts, N, S):
+    return {"iters": len(ts), "s_per_frame_median": statistics.median(ts), "s_per_frame_min": min(ts),
+            "s_per_frame_max": max(ts), "gaussians_per_s": N / statistics.median(ts),
+            "instances_per_s": N * S / statistics.median(ts)}
+
+
+def cpu_baseline(name, channels, full=False):
+    """The build's CPU restatement of the path (the reference has NO CPU path: flow3d/scene_model.py:36,360), timed on
+    this box's host cores as BASELINE.md section 3 plans: the same seeded frame, forward + backward, (i) through the
+    scalar-C restatement with the S sub-samples on parallel threads and (ii) through the all-thread torch restatement;
+    cfg1 in full, the headline config on a bounded number of iterations (default run: ~30 s of CPU work; the whole plan
+    with --cpu-baseline-full, committed under profiles/)."""
+    host = os.cpu_count()
+    out = {"unit": "Gaussians/s", "kind": "port", "cpu_model": _cpu_model(), "host_cores": host, "runs": {}}
+    # default run: scalar C only (cfg1 x 20 + the benched config x 3: ~20 s); the torch restatement is minutes per frame
+    # and belongs to the full plan, whose output is committed under profiles/
+    plan = [("cfg1", "scalar_c", 20)]
+    if full:
+        plan += [("cfg1", "torch", 20)]
+    if name != "cfg1":
+        plan += [(name, "scalar_c", 3 if full or name in ("cfg2", "tiny", "refdefault") else 1)]
+        if full:
+            plan += [(name, "torch", 3 if name == "cfg2" else 1)]
+    for cfgname, impl, iters in plan:
+        N, G, K, S, W, H = CONFIGS[cfgname]
+        sc = scene_of(cfgname, channels=channels if cfgname == name else 3)
+        threads = min(S, host)
+        ts, n_isect = [], None
+        for _ in range(iters):
+            if impl == "scalar_c":
+                t, n_isect = _cpu_frame_scalar_c(sc, cfgname, threads)
+            else:
+                t = _cpu_frame_torch(sc, cfgname)
+            ts.append(t)
+        r = _stats(ts, N, S)
+        r["cores"] = threads if impl == "scalar_c" else min(TORCH_CPU_THREADS, host)
+        if n_isect is not None:
+            r["n_isect"] = n_isect
+        out["runs"][f"{cfgname}/{impl}"] = r
+    head = out["runs"][f"{name}/scalar_c"]
+    N, G, K, S, W, H = CONFIGS[name]
+    out.update(value=head["gaussians_per_s"], cores=head["cores"],
+               sample=f"{head['iters']} full frame(s) of {name} ({N} Gaussians, {W}x{H}, S={S}), forward + backward through "
+                      f"oracle/raster_ref.c (scalar C, fp32) with the {S} sub-samples on {head['cores']} parallel threads + torch "
+                      f"deformation; median {head['s_per_frame_median']:.2f} s per frame (min {head['s_per_frame_min']:.2f}, max "
+                      f"{head['s_per_frame_max']:.2f}); `runs` holds cfg1 in full (20 iterations); the torch restatement's leg "
+                      f"of BASELINE.md section 3 runs with --cpu-baseline-full (profiles/r02_cpu_baseline_full.json)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ roofline helpers
+def _load_json(*rel):
+    try:
+        return json.load(open(os.path.join(ROOT, *rel)))
+    except Exception:
+        return None
+
+
+def _traffic(name, kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs, KB
+    units; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-counts wide coalesced reads up to 2x, so the read term is
+    reported both ways)."""
+    pm = (_load_json("profiles", "pmc_traffic.json") or {}).get(name, {}).get("kernels", {}).get(kernel)
+    if not pm:
+        return None
+    f, w = pm["FETCH_SIZE"] * 1024.0, pm["WRITE_SIZE"] * 1024.0
+    return {"fetch_1x": f, "fetch_2x": 2 * f, "write": w, "total_1x": f + w, "total_2x": 2 * f + w}
 
 
 def main():
@@ -140,7 +268,7 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the pool's driver only supports dmabuf IPC
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
@@ -151,28 +279,12 @@ def main():
 
     name = args.config
     N, G, K, S, W, H = CONFIGS[name]
-    views = world > 1 and args.shard == "views"
-    sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0, channels=args.channels)
-    bg = torch.ones(args.channels, device=dev)
-    sharder = None
-    if use_dist:
-        sharder = ShardedExposure(world, rank, mode=args.shard)
-
-    last = {}
-
-    def step():
-        for v in leaves.values():
-            v.grad = None
-        if sharder is None:
-            res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
-                                  leaves["colors"], 3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
-                                  leaves["times"], leaves["RTs"], leaves["viewmat"], d["K"], W, H, background=bg,
-                                  return_depth=True)
-            loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
-            loss.backward()
-        else:
-            res = sharder.step(leaves, d["K"], W, H, bg, wimg, wacc)
-        last["res"] = res
+    channels = args.channels or (16 if name.startswith("refdefault") else 3)
+    if use_dist and args.shard == "exposure" and world > S:
+        raise SystemExit(f"--shard exposure needs world_size <= S ({world} > {S})")
+    bg = torch.ones(channels, device=dev)
+    lib = L.lib()
+    prof = not args.no_profile
 
     def sync():
         if use_dist:
@@ -181,18 +293,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    lib = L.lib()
-    prof = not args.no_profile
-    sync()
-    if prof:
-        lib.d4gs_profile_enable(2)  # HIP events around the rasterization kernels only: timing EVERY kernel costs two
-    t0 = time.perf_counter()      # stream events per launch, ~0.12 ms of a 1.6 ms frame
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
     def collect():
         lib.d4gs_profile_enable(0)
         buf = C.create_string_buffer(1 << 16)
@@ -203,42 +303,86 @@ def main():
             got[nm] = (int(cnt), float(ms))
         return got
 
-    kern, kern_all, n_break = {}, {}, 0
-    if prof:
-        kern = collect()  # the dominant kernels, measured live over the timed region
-        n_break = min(args.steps, 10)  # untimed extra pass with every kernel timed: the full per-kernel breakdown
-        lib.d4gs_profile_enable(1)
-        for _ in range(n_break):
+    def measure(mode, steps, warmup, profile):
+        """-> (seconds for `steps` steps: max over ranks, live kernel timings, last state)"""
+        views = use_dist and mode == "views"
+        sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0, channels=channels,
+                                                scale_mul=args.scale_mul)
+        sharder = ShardedExposure(world, rank, mode=mode) if use_dist else None
+        last = {}
+
+        def step():
+            for v in leaves.values():
+                v.grad = None
+            if sharder is None:
+                res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
+                                      leaves["colors"], 3, leaves.get("motion_coefs"), leaves.get("rots"),
+                                      leaves.get("transls"), leaves.get("times"), leaves["RTs"], leaves["viewmat"], d["K"],
+                                      W, H, background=bg, return_depth=True)
+                loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
+                loss.backward()
+                last["st"] = res["state"]
+            else:
+                last["st"] = sharder.step(leaves, d["K"], W, H, bg, wimg, wacc)
+
+        for _ in range(warmup):
             step()
         sync()
-        kern_all = collect()
-    if use_dist:
-        import torch.distributed as dist
+        if profile:
+            lib.d4gs_profile_enable(2)  # HIP events around the rasterization kernels only: timing EVERY kernel costs two
+        t0 = time.perf_counter()      # stream events per launch, ~0.12 ms of a 1.6 ms frame
+        for _ in range(steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+        kern, kern_all, n_break = {}, {}, 0
+        if profile:
+            kern = collect()  # the dominant kernels, measured live over the timed region
+            n_break = min(steps, 10)  # untimed extra pass with every kernel timed: the full per-kernel breakdown
+            lib.d4gs_profile_enable(1)
+            for _ in range(n_break):
+                step()
+            sync()
+            kern_all = collect()
+        if use_dist:
+            import torch.distributed as dist
 
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kern, kern_all, n_break, last["st"]
+
+    dt, kern, kern_all, n_break, st = measure(args.shard, args.steps, args.warmup, prof)
+    views_primary = use_dist and args.shard == "views"
     ms_step = 1e3 * dt / args.steps
-    frames_per_step = world if views else 1
-    value = frames_per_step * N / (dt / args.steps)
-
+    value = (world if views_primary else 1) * N / (dt / args.steps)
+    metric = "Gaussians/s fwd+bwd, 288x512, N_exposure=8" if name == "cfg2" else f"Gaussians/s fwd+bwd ({name})"
     out = {
-        "metric": "Gaussians/s fwd+bwd, 288x512, N_exposure=8" if name == "cfg2" else f"Gaussians/s fwd+bwd ({name})",
-        "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if args.shard == "views" else "strong",
+        "metric": metric, "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if views_primary else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}: {N} Gaussians ({G} dynamic), {K} motion bases, {W}x{H}, N_exposure={S}, "
-                                f"{args.channels}+depth channels, fwd+bwd to all leaves", "gaussians": N, "exposure_subsamples": S,
-                   "parallelism": "1 GPU" if world == 1 else f"{args.shard}-sharded x{world} (RCCL)"},
+                                f"{channels}+depth channels, fwd+bwd to all leaves"
+                                + (f", extents x{args.scale_mul:g}" if args.scale_mul != 1.0 else ""),
+                   "gaussians": N, "exposure_subsamples": S,
+                   "parallelism": "1 GPU" if world == 1 else
+                   (f"BASELINE cfg4: exposure sub-samples sharded x{world}, RCCL blend + gradient all-reduce"
+                    if not views_primary else f"views sharded x{world} (data parallel), RCCL gradient all-reduce")},
         "instances_per_s": value * S,
     }
+    if world > 1 and not views_primary:  # secondary: data-parallel over camera views (weak scaling), same protocol
+        dt_v, _, _, _, _ = measure("views", args.steps, args.warmup, False)
+        out["views_weak_scaling"] = {"value": world * N / (dt_v / args.steps), "unit": "Gaussians/s", "scaling": "weak",
+                                     "ms_per_step": 1e3 * dt_v / args.steps,
+                                     "note": "every rank renders its own full frame (one camera view per GPU), flat "
+                                             "gradient all-reduce; NOT BASELINE's cfg4"}
     if rank == 0:
-        st = last["res"]["state"] if isinstance(last["res"], dict) else last["res"]
         n_isect = st.n_isect
         S_loc = st.cfg.S
-        out["n_isect_per_step"] = n_isect if sharder is None else None
+        out["n_isect_per_step"] = n_isect if world == 1 else None
         if kern:
-            out["kernels_ms_per_step"] = {k: v[1] / n_break for k, v in sorted(kern_all.items(), key=lambda kv: -kv[1][1])}
+            per = {k: v[1] / n_break for k, v in sorted(kern_all.items(), key=lambda kv: -kv[1][1])}
+            out["kernels_ms_per_step"] = per
             out["kernels_note"] = (f"per-kernel breakdown from {n_break} extra untimed steps with every kernel bracketed by "
                                    "HIP events; the roofline kernel's duration comes from the timed region itself")
             dom = max(kern.items(), key=lambda kv: kv[1][1])[0]
@@ -252,40 +396,77 @@ def main():
             tmax = pad.view(S_loc, th, 16, tw, 16).amax(dim=(2, 4)).reshape(-1)
             cnts = (to[1:] - to[:-1])
             proc_bwd = torch.where(cnts > 0, (tmax - to[:-1] + 1).clamp(min=0), torch.zeros_like(cnts))
-            pairs_bwd = float(proc_bwd.sum().item()) * 256.0
-            R = 6 + args.channels + 1
+            isect_replayed = float(proc_bwd.sum().item())
+            pairs_bwd = isect_replayed * 256.0
+            R = 6 + channels + 1
             # algorithmic bytes of k_raster_bwd (DESIGN.md "roofline"): per intersection replayed: id 4 + emit 4 +
-            # geom 32 + colours 16 read, gradient row R*4 written; per pixel: v_out 16 + v_alpha 4 + alpha 4 +
-            # last_id 4 + out 16 read.
-            bytes_bwd = float(proc_bwd.sum().item()) * (4 + 4 + 32 + 16 + R * 4) + S_loc * H * W * 44.0
-            traffic = None
-            try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (MI355X_MICROARCH.md, HBM section)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[name]["kernels"][dom]
-                if args.channels == 3:
-                    traffic = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-            except Exception:
-                traffic = None
+            # geom 32 + colours 4*DP read, gradient row R*4 written; per pixel: v_out + v_alpha + alpha + last_id + T + out.
+            DP = (channels + 3) // 4 * 4
+            bytes_bwd = isect_replayed * (4 + 4 + 32 + 4 * DP + R * 4) + S_loc * H * W * (8.0 * (channels + 1) + 16.0)
             if dom.startswith("k_raster"):
                 flops = pairs_bwd * (FLOPS_PER_PAIR_BWD if "bwd" in dom else FLOPS_PER_PAIR_FWD)
-                out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": flops / t_k / 1e12,
-                                   "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS,
-                                   "traffic": traffic, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
-                                   "traffic_note": "FETCH_SIZE + WRITE_SIZE (KB) x 1024 from separate rocprofv3 --pmc passes "
-                                                   "(profiles/pmc_traffic.json); gfx950's FETCH_SIZE can under-count wide "
-                                                   "coalesced reads 2x, so true read traffic lies between 1x and 2x the "
-                                                   "fetch term",
-                                   "note": "fp32 VALU-bound composite; algorithmic ops of the reference per (splat, pixel) "
-                                           "of each 16x16 tile x pairs replayed; fp32 vector peak == fp32-input dense "
-                                           "MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); no MFMA is issued"}
+                tr = _traffic(name, dom) if channels == 3 and args.scale_mul == 1.0 else None
+                roof = {"kernel": dom, "bound": "mfma", "bound_actual": "fp32 VALU issue (no MFMA is issued; the contract's "
+                        "field only admits hbm|mfma and 157.3 TFLOP/s is both the fp32 vector and the fp32-input MFMA peak)",
+                        "achieved": flops / t_k / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS, "traffic": tr["total_1x"] if tr else None,
+                        "traffic_detail": tr, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
+                        "note": "NOMINAL work-equivalent fraction (SURVEY 8d): 90 flop x 256 pixels for every (tile, splat) "
+                                "pair the kernel replays, although the kernel skips most of those pixels by design; the "
+                                "`hardware` object below says what the VALU actually does"}
+                # what the hardware does, from the committed PMC pass + the offline lane statistics of the same scene
+                sq = (_load_json("profiles", "r02_pmc_sq_cfg2.json") or {}).get(dom) if name == "cfg2" and channels == 3 else None
+                lanes = _load_json("profiles", "r02_lane_stats_cfg2.json") if name == "cfg2" and channels == 3 else None
+                if sq:
+                    clk_cycles = sq["GRBM_GUI_ACTIVE"] / N_XCD  # the counter is summed over the 8 XCDs
+                    insts = sq["SQ_INSTS_VALU"]
+                    hw = {"source": "profiles/r02_pmc_sq_cfg2.json (rocprofv3 --pmc, own pass), profiles/r02_lane_stats_cfg2.json",
+                          "valu_wave_insts_per_launch": insts, "kernel_cycles": clk_cycles,
+                          "cycles_per_valu_inst_per_simd": clk_cycles * N_SIMD / insts,
+                          "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] / (clk_cycles * N_CU),
+                          "fp32_rate_if_every_inst_were_a_full_fma_tflops": insts * 64 * 2 / t_k / 1e12}
+                    if lanes:
+                        af = lanes["bwd_active_lane_fraction"]
+                        vp = lanes["bwd_valid_pairs"] * (isect_replayed / max(lanes["n_isect"], 1))
+                        replayed_lanes = lanes["bwd_quadrant_replays"] * 64.0 * (isect_replayed / max(lanes["n_isect"], 1))
+                        nec = vp * FLOPS_PER_PAIR_BWD + (replayed_lanes - vp) * FLOPS_INVALID_PAIR
+                        hw.update(active_lane_fraction=af, replays_with_no_valid_lane=lanes["bwd_replays_with_no_valid_lane"],
+                                  necessary_flops_per_launch=nec, necessary_tflops=nec / t_k / 1e12,
+                                  frac_necessary=nec / t_k / 1e12 / F32_PEAK_TFLOPS,
+                                  necessary_note="90 flop only for lanes that pass the alpha test, 12 for the other lanes "
+                                                 "of a replayed (quadrant, splat) pair")
+                    roof["hardware"] = hw
+                out["roofline"] = roof
                 out["roofline_hbm"] = {"kernel": dom, "bound": "hbm", "achieved": bytes_bwd / t_k / 1e9,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_bwd / t_k / 1e9 / HBM_PEAK_GBS,
-                                       "traffic": traffic, "algorithmic_bytes": bytes_bwd}
+                                       "traffic": tr["total_1x"] if tr else None, "algorithmic_bytes": bytes_bwd}
             else:
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": t_k * 1e3}
+            # the streaming kernels against HBM: algorithmic bytes / live duration
+            SN, n_i = float(S_loc) * N, float(n_isect)
+            alg = {
+                "k_project_fwd": N * (12 + 16 + 12 + 4 + 4 * channels) + G * 4 * K + SN * (8 + 4 + 12 + 4 + 32 + 8 + 4)
+                                 + N * (4 + 4 * DP),
+                "k_emit": SN * (4 + 8 + 4 + 4) + n_i * (8 + 4),
+                "k_gather": n_i * R * 4 + SN * (8 + 8 + 12 + 4) + N * (4 + 4 * DP),
+                "k_project_bwd": N * (12 + 16 + 12 + 4 + 4 * channels) * 2 + G * 8 * K + SN * (4 + 12 + 8 + 12 + 4)
+                                 + N * (8 + 8 * DP),
+                "k_tile_sort": n_i * (8 + 4 + 4 + 4),
+            }
+            stream = []
+            for kname, b in alg.items():
+                if kname in per and per[kname] > 0:
+                    tk = per[kname] * 1e-3
+                    tr = _traffic(name, kname) if channels == 3 and args.scale_mul == 1.0 else None
+                    stream.append({"kernel": kname, "bound": "hbm", "algorithmic_bytes": b, "avg_launch_ms": per[kname],
+                                   "achieved": b / tk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / tk / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": tr["total_2x"] if tr else None, "traffic_detail": tr,
+                                   "traffic_frac_of_peak": (tr["total_2x"] / tk / 1e9 / HBM_PEAK_GBS) if tr else None})
+            out["roofline_streaming"] = stream
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(name)
+                out["cpu_baseline"] = cpu_baseline(name, channels, full=args.cpu_baseline_full)
             except Exception as e:  # the checker must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "Gaussians/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}

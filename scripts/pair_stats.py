@@ -72,6 +72,7 @@ for a0 in range(0, n, CH):
     lastq = lastp.reshape(-1, 2, 8, 2, 8).permute(0, 1, 3, 2, 4).reshape(-1, 4, 64).max(-1).values
     hit_k = hit & (idx_in_list[sl, None] <= lastq)            # what the backward kernel replays today
     K_hits += int(hit_k.sum()); K_zero += int((vq[hit_k] == 0).sum()); K_geo_zero += int((gq[hit_k] == 0).sum())
+    K_valid = (K_valid if "K_valid" in globals() else 0) + int(vq[hit_k].sum())
     gb = geo.view(-1, 4, 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 16, 16).sum(-1)
     lastb = lastp.reshape(-1, 4, 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 16, 16).max(-1).values
     # ---- 4x4 blocks: 16 per tile; row r of quadrant q handles block (q, r)
@@ -132,3 +133,15 @@ for nb in NCHK:
     cg = chunk_cnt_g[nb].view(-1, NCHK[nb], 2, 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(-1, NCHK[nb], 4, 4)
     print(f"batch {nb}: quadrant iterations today {int(chunk_q[nb].sum())}; 4-row scheme sum over (batch, wave) of max row: "
           f"{int(c.max(-1).values.sum())} (box), {int(cg.max(-1).values.sum())} (exact); per-wave barrier-max over waves (box): {int(c.max(-1).values.max(-1).values.sum() * 4)}")
+
+import json
+stats = {"config": "cfg2 (seed 0 scene of the same distribution)", "n_isect": int(n),
+         "bwd_quadrant_replays": int(K_hits), "bwd_replays_with_no_valid_lane": K_zero / K_hits,
+         "bwd_valid_pairs": int(K_valid), "bwd_active_lane_fraction": K_valid / (64.0 * K_hits),
+         "bwd_active_lane_fraction_of_nonempty_replays": K_valid / (64.0 * (K_hits - K_zero)),
+         "fwd_quadrant_replays_by_box": int(tot_q), "fwd_valid_pairs": int(tot_valid),
+         "note": "valid = alpha >= 1/255, sigma >= 0, inside the image, at or before the pixel's last contributor; a replay = "
+                 "one (8x8 quadrant wave, splat) iteration of k_raster_bwd_q"}
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(stats, open("gpurun_out/lane_stats_cfg2.json", "w"), indent=1)
+print(json.dumps(stats))
