@@ -20,6 +20,7 @@ import torch
 
 from . import _lib as L
 from .engine import _stream
+from .rows import RowPlan
 
 
 @torch.no_grad()
@@ -89,18 +90,20 @@ def _swap_param(optimizer, i: int, p_new, edit_state):
     return True
 
 
-def dup_in_optim(optimizer, new_params: list, should_split: torch.Tensor, num_new: int):
-    """Adam moments after `densify_params`: rows of the kept Gaussians, then zeros for every new row."""
+def dup_in_optim(optimizer, new_params: list, plan: RowPlan):
+    """Adam moments after `densify_params` (trainer.py:1199-1217): rows of the kept Gaussians, then zeros for every new
+    row - the same RowPlan as the parameters, gathered with `zero_new`."""
     assert len(optimizer.param_groups) == len(new_params)
     for i, p in enumerate(new_params):
-        if not _swap_param(optimizer, i, p, lambda m: torch.cat([m[~should_split], m.new_zeros(num_new, *m.shape[1:])], 0)):
+        if not _swap_param(optimizer, i, p, lambda m: plan.gather(m, zero_new=True)):
             return
 
 
-def remove_from_optim(optimizer, new_params: list, should_cull: torch.Tensor):
+def remove_from_optim(optimizer, new_params: list, plan: RowPlan):
+    """trainer.py:1219-1236."""
     assert len(optimizer.param_groups) == len(new_params)
     for i, p in enumerate(new_params):
-        if not _swap_param(optimizer, i, p, lambda m: m[~should_cull]):
+        if not _swap_param(optimizer, i, p, plan.gather):
             return
 
 
@@ -140,24 +143,20 @@ def densify_step(model, running_stats: dict, optimizers: dict, cfg: ControlCfg, 
     dup = grad_high & ~scale_big
     nfg = model.num_fg_gaussians
     masks = {"fg": (split[:nfg], dup[:nfg]), "bg": (split[nfg:], dup[nfg:])}
-    for name, part in _parts(model, only_fg):
-        sp, du = masks[name]
-        n_new = 2 * int(sp.sum()) + int(du.sum())
-        for pname, p_new in part.densify_params(sp, du).items():
+    plans = {}
+    for name, part in _parts(model, only_fg):  # one compaction plan per Gaussian set serves parameters, Adam moments
+        sp, du = masks[name]                   # and statistics
+        plans[name] = plan = RowPlan(sp, du)
+        for pname, p_new in part.densify_params(sp, du, plan=plan).items():
             opt = optimizers.get(f"{name}.params.{pname}")
             if opt is not None:
-                dup_in_optim(opt, [p_new], sp, n_new)
+                dup_in_optim(opt, [p_new], plan)
     for k, v in running_stats.items():  # same row order as densify_params: kept, duplicated, split twice
         chunks = []
         for name, lo, hi in (("fg", 0, nfg), ("bg", nfg, v.shape[0])):
-            part_v = v[lo:hi]
-            if name == "bg" and (only_fg or model.bg is None):
-                chunks.append(part_v)
-                continue
-            sp, du = masks[name]
-            chunks += [part_v[~sp], part_v[du], part_v[sp].repeat(2)]
+            chunks.append(plans[name].gather(v[lo:hi]) if name in plans else v[lo:hi])
         running_stats[k] = torch.cat(chunks, 0)
-    return int(split.sum()), int(dup.sum())
+    return sum(p.n_split for p in plans.values()), sum(p.n_dup for p in plans.values())
 
 
 @torch.no_grad()
@@ -173,16 +172,19 @@ def cull_step(model, running_stats: dict, optimizers: dict, cfg: ControlCfg, glo
         if global_step < cfg.stop_control_by_screen_steps:
             cull = cull | (running_stats["max_radii"] > cfg.cull_screen_threshold)
     masks = {"fg": cull[:nfg], "bg": cull[nfg:]}
+    plans = {}
     for name, part in _parts(model, only_fg):
-        for pname, p_new in part.cull_params(masks[name]).items():
+        plans[name] = plan = RowPlan(masks[name])
+        for pname, p_new in part.cull_params(masks[name], plan=plan).items():
             opt = optimizers.get(f"{name}.params.{pname}")
             if opt is not None:
-                remove_from_optim(opt, [p_new], masks[name])
-    if only_fg:
-        cull = torch.cat([masks["fg"], torch.zeros_like(masks["bg"])], 0)
+                remove_from_optim(opt, [p_new], plan)
     for k, v in running_stats.items():
-        running_stats[k] = v[~cull]
-    return int(cull.sum())
+        chunks = []
+        for name, lo, hi in (("fg", 0, nfg), ("bg", nfg, v.shape[0])):
+            chunks.append(plans[name].gather(v[lo:hi]) if name in plans else v[lo:hi])
+        running_stats[k] = torch.cat(chunks, 0)
+    return sum(p.n_in - p.n_keep for p in plans.values())
 
 
 @torch.no_grad()

@@ -16,6 +16,8 @@ int d4gs_points_fwd_impl(const D4gsDims *, const D4gsProjIn *, float *, hipStrea
 int d4gs_points_bwd_impl(const D4gsDims *, const D4gsProjIn *, const float *, const D4gsLeafGrads *, hipStream_t);
 int d4gs_control_stats_impl(int32_t, int32_t, const float *, const int32_t *, int32_t, int32_t, int32_t, float *,
                             int64_t *, float *, int32_t, hipStream_t);
+int d4gs_control_plan_impl(int32_t, const uint8_t *, const uint8_t *, int32_t *, int32_t *, hipStream_t);
+int d4gs_gather_rows_impl(const int32_t *, int64_t, int32_t, const float *, float *, int64_t, int64_t, float, hipStream_t);
 int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *,
                         hipStream_t);
 int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
@@ -224,6 +226,10 @@ int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
     d4gs_set_error("d4gs_raster_bwd: NULL forward state or gradient buffer");
     return D4GS_EINVAL;
   }
+  if (g->stats_grad_norm_acc && (!g->stats_vis_count || !g->stats_max_radii || !proj->radii || g->stats_batch_size <= 0)) {
+    d4gs_set_error("d4gs_raster_bwd: fused statistics need vis_count, max_radii, radii and a positive batch size");
+    return D4GS_EINVAL;
+  }
   return d4gs_raster_bwd_impl(dims, proj, isect, r, g, (hipStream_t)stream);
 }
 
@@ -285,6 +291,24 @@ int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad, const int32_
                        int32_t update_max_radii, void *stream) {
   return d4gs_control_stats_impl(S, N, xys_grad, radii, width, height, batch_size, grad_norm_acc, vis_count, max_radii,
                                  update_max_radii, (hipStream_t)stream);
+}
+
+int d4gs_control_plan(int32_t N, const uint8_t *split_or_cull, const uint8_t *dup, int32_t *src_map, int32_t *counts,
+                      void *stream) {
+  if (N <= 0 || !split_or_cull || !src_map || !counts) {
+    d4gs_set_error("d4gs_control_plan: bad argument (N=%d)", N);
+    return D4GS_EINVAL;
+  }
+  return d4gs_control_plan_impl(N, split_or_cull, dup, src_map, counts, (hipStream_t)stream);
+}
+
+int d4gs_gather_rows(const int32_t *src_map, int64_t n_out, int32_t row_floats, const float *in, float *out,
+                     int64_t zero_from, int64_t add_from, float add, void *stream) {
+  if (n_out < 0 || row_floats <= 0 || (n_out > 0 && (!src_map || !in || !out))) {
+    d4gs_set_error("d4gs_gather_rows: bad argument (n_out=%lld row_floats=%d)", (long long)n_out, row_floats);
+    return D4GS_EINVAL;
+  }
+  return d4gs_gather_rows_impl(src_map, n_out, row_floats, in, out, zero_from, add_from, add, (hipStream_t)stream);
 }
 
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy, const float *renders,

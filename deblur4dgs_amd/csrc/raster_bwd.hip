@@ -750,6 +750,13 @@ struct GatherArgs {
   const int32_t *isect_offsets;
   const float *isect_grad;
   float *v_means2d, *v_conics, *v_depths, *v_opac_act, *v_ctab;
+  // fused densification statistics (trainer.py:967-989); stats_acc == nullptr: off
+  const int32_t *radii;
+  float *stats_acc;
+  int64_t *stats_vis;
+  float *stats_mr;
+  float sx, sy, max_wh;
+  int update_mr;
 };
 
 // The rows of the 64 instances a wave owns (same sub-sample, consecutive Gaussians) form ONE contiguous span of
@@ -769,6 +776,11 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   float vo = 0.f, vc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) vc[c] = 0.f;
+  // densification statistics of this Gaussian, accumulated over the sub-samples in order (k_control_stats' arithmetic)
+  const bool stats = a.stats_acc != nullptr;
+  float st_acc = 0.f, st_mr = 0.f;
+  int64_t st_vis = 0;
+  if (stats && in) st_acc = a.stats_acc[g], st_vis = a.stats_vis[g], st_mr = a.stats_mr[g];
   for (int s = 0; s < a.S; s++) {
     const size_t i = (size_t)s * a.N + (in ? g : a.N - 1);
     const int cnt = in ? a.tiles_touched[i] : 0;
@@ -803,12 +815,26 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
       a.v_conics[i * 3 + 1] = acc[3];
       a.v_conics[i * 3 + 2] = acc[4];
       a.v_depths[i] = DEPTH ? acc[6 + (DEPTH ? D : 0)] : 0.f;
+      if (stats) {
+        const int r = a.radii[i];
+        if (r > 0) {
+          const float gx = acc[0] * a.sx, gy = acc[1] * a.sy;
+          st_acc += sqrtf(gx * gx + gy * gy);
+          st_vis += 1;
+          st_mr = fmaxf(st_mr, (float)r / a.max_wh);
+        }
+      }
     }
     vo += acc[5];
 #pragma unroll
     for (int c = 0; c < D; c++) vc[c] += acc[6 + c];
   }
   if (!in) return;
+  if (stats) {
+    a.stats_acc[g] = st_acc;
+    a.stats_vis[g] = st_vis;
+    if (a.update_mr) a.stats_mr[g] = st_mr;
+  }
   a.v_opac_act[g] = vo;
 #pragma unroll
   for (int c = 0; c < DP; c++) a.v_ctab[(size_t)g * DP + c] = c < D ? vc[c < D ? c : 0] : 0.f;
@@ -863,6 +889,12 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   ga.tiles_touched = proj->tiles_touched, ga.isect_offsets = proj->isect_offsets, ga.isect_grad = g->isect_grad;
   ga.v_means2d = g->v_means2d, ga.v_conics = g->v_conics, ga.v_depths = g->v_depths, ga.v_opac_act = g->v_opac_act;
   ga.v_ctab = g->v_ctab;
+  ga.radii = proj->radii, ga.stats_acc = g->stats_grad_norm_acc, ga.stats_vis = g->stats_vis_count;
+  ga.stats_mr = g->stats_max_radii, ga.update_mr = g->stats_update_max_radii;
+  // xys_grad[..., 0] *= W / 2 * batch_size * S ; [..., 1] *= H / 2 * batch_size * S   (trainer.py:976-977)
+  ga.sx = (float)dims->width / 2.0f * (float)g->stats_batch_size * (float)dims->S;
+  ga.sy = (float)dims->height / 2.0f * (float)g->stats_batch_size * (float)dims->S;
+  ga.max_wh = (float)(dims->width > dims->height ? dims->width : dims->height);
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
 #define D4GS_CASE(DD)                                                                             \
   case DD:                                                                                        \

@@ -45,6 +45,9 @@ class RenderCfg:
     optimistic_sizes: bool = True  # size the intersection lists from the previous call's count, verify afterwards
     grad_arena: dict | None = None  # optional {"means": tensor, ...}: leaf gradients are written THERE (e.g. views of
     #                                  a flat all-reduce buffer) instead of fresh tensors; shapes / dtype must match
+    control_stats: dict | None = None  # optional densification-statistics sink, updated by the backward's gather epilogue
+    #                                  (SURVEY 8f-1): {"xys_grad_norm_acc" f32[N], "vis_count" i64[N], "max_radii" f32[N],
+    #                                  "batch_size" int, "update_max_radii" bool}
 
     @property
     def DP(self) -> int:
@@ -250,6 +253,16 @@ class ProjectFn(torch.autograd.Function):
         return (None, *outs, None)
 
 
+def _check_stats(cs: dict, N: int) -> dict:
+    acc, vis, mr = cs["xys_grad_norm_acc"], cs["vis_count"], cs["max_radii"]
+    if not (acc.dtype == torch.float32 and vis.dtype == torch.int64 and mr.dtype == torch.float32 and
+            acc.shape == vis.shape == mr.shape == (N,) and acc.is_contiguous() and vis.is_contiguous() and mr.is_contiguous()):
+        raise ValueError(f"control_stats: need contiguous xys_grad_norm_acc f32 / vis_count i64 / max_radii f32 of shape ({N},)")
+    if int(cs["batch_size"]) <= 0:
+        raise ValueError("control_stats: batch_size must be positive")
+    return cs
+
+
 class RasterFn(torch.autograd.Function):
     """Composite one channel chunk.  `cfg` is the chunk's configuration (its D = the kernel width, depth mode set on
     the last chunk only); the projection outputs and the sorted tile lists come from the shared `st`.  The first chunk
@@ -338,6 +351,11 @@ class RasterFn(torch.autograd.Function):
         isect.n_isect, isect.max_tile_count = st.n_isect, st.max_tile
         ras = L.fill(L.Raster(), **rst)
         rg = L.fill(L.RasterGrads(), **g)
+        if cfg.control_stats is not None:  # fused statistics: the gather epilogue owns v_means2d and reads radii
+            cs = _check_stats(cfg.control_stats, N)
+            rg.stats_grad_norm_acc, rg.stats_vis_count = L.ptr(cs["xys_grad_norm_acc"]), L.ptr(cs["vis_count"])
+            rg.stats_max_radii = L.ptr(cs["max_radii"])
+            rg.stats_batch_size, rg.stats_update_max_radii = int(cs["batch_size"]), int(bool(cs.get("update_max_radii", False)))
         L.check(lib.d4gs_raster_bwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), C.byref(rg), _stream()),
                 "d4gs_raster_bwd")
         return None, None, g["v_means2d"], g["v_conics"], g["v_depths"], g["v_opac_act"], g["v_ctab"], None
@@ -437,10 +455,22 @@ def render_instances(cfg: RenderCfg, means, quats, scales, opacities, colors, mo
     # (gsplat renders wide feature vectors in `channel_chunk`-sized passes the same way); autograd sums the chunks'
     # per-instance gradients.  Only the first chunk's alpha is differentiated (they are all the same numbers).
     F = torch.nn.functional
+    if cfg.control_stats is not None and means2d.requires_grad:
+        # the statistics need the TOTAL means2d gradient (autograd sums the chunks): separate pass on that sum
+        cs = _check_stats(cfg.control_stats, cfg.N)
+
+        def _stats(gsum, cs=cs, radii=radii, cfg=cfg):
+            with torch.no_grad():
+                L.check(L.lib().d4gs_control_stats(cfg.S, cfg.N, L.ptr(gsum.to(torch.float32).contiguous()), L.ptr(radii),
+                                                   cfg.width, cfg.height, int(cs["batch_size"]), L.ptr(cs["xys_grad_norm_acc"]),
+                                                   L.ptr(cs["vis_count"]), L.ptr(cs["max_radii"]),
+                                                   int(bool(cs.get("update_max_radii", False))), _stream()), "d4gs_control_stats")
+
+        means2d.register_hook(_stats)
     outs, ra = [], None
     for k, (c0, c1, Dk) in enumerate(chunks):
         last = k == len(chunks) - 1
-        ck = replace(cfg, D=Dk, depth_mode=cfg.depth_mode if last else L.DEPTH_NONE, grad_arena=None)
+        ck = replace(cfg, D=Dk, depth_mode=cfg.depth_mode if last else L.DEPTH_NONE, grad_arena=None, control_stats=None)
         tab = F.pad(ctab[:, c0:c1], (0, ck.DP - (c1 - c0)))
         bgk = None if background is None else F.pad(background.to(torch.float32).reshape(-1)[c0:c1], (0, Dk - (c1 - c0)))
         rck, rak = RasterFn.apply(st, ck, means2d, conics, depths, opac_act, tab, bgk)

@@ -74,23 +74,28 @@ class GaussianParams(nn.Module):
 
 
     # ---- adaptive control (flow3d/params.py:86-118): the model side of densify / cull / reset ----------------
-    def densify_params(self, should_split, should_dup):
+    def densify_params(self, should_split, should_dup, plan=None):
         """Row surgery on every parameter: kept rows (not split), then the duplicated rows, then every split row twice
-        (the two halves of a split get scales / 1.6, i.e. log-scale - log 1.6).  Returns {name: new Parameter}."""
+        (the two halves of a split get scales / 1.6, i.e. log-scale - log 1.6).  Returns {name: new Parameter}.
+        One RowPlan (stream compaction on the device) serves all parameters; pass `plan` to share it with the Adam
+        state / statistics surgery of the same step."""
+        from .rows import SPLIT_LOG_SCALE, RowPlan
+
+        plan = plan or RowPlan(should_split, should_dup)
         out = {}
         for name in list(self.params.keys()):
-            x = self.params[name]
-            halves = x[should_split].repeat(2, *([1] * (x.ndim - 1)))
-            if name == "scales":
-                halves = halves - math.log(1.6)
-            out[name] = nn.Parameter(torch.cat([x[~should_split], x[should_dup], halves], 0))
+            out[name] = nn.Parameter(plan.gather(self.params[name].detach(),
+                                                 split_add=SPLIT_LOG_SCALE if name == "scales" else None))
             self.params[name] = out[name]
         return out
 
-    def cull_params(self, should_cull):
+    def cull_params(self, should_cull, plan=None):
+        from .rows import RowPlan
+
+        plan = plan or RowPlan(should_cull)
         out = {}
         for name in list(self.params.keys()):
-            out[name] = nn.Parameter(self.params[name][~should_cull])
+            out[name] = nn.Parameter(plan.gather(self.params[name].detach()))
             self.params[name] = out[name]
         return out
 
@@ -140,6 +145,27 @@ class SceneModel(nn.Module):
         self._current_xys = self._current_radii = self._current_img_wh = None
         self.move_model = MoveModel(num_fg=self.num_fg_gaussians, camera_mode="linear").to(Ks.device)
         self.inplace_blend_quirk = True  # exposure_imgs[-1] is the blended frame (scene_model.py:391,486)
+        self._stats_sink = None
+
+    def attach_control_stats(self, running_stats: dict, batch_size: int, update_max_radii: bool = False):
+        """SURVEY 8f-1, fused: until `detach_control_stats()`, the backward of every full render (all Gaussians, no
+        filter mask) adds this step's densification statistics to `running_stats` inside the rasterizer's gather
+        epilogue - what `Trainer._prepare_control_step` (flow3d/trainer.py:953-990) computes from
+        `_current_xys[i].grad` / `_current_radii` after the step, without the S x 10 torch launches or the extra pass.
+        `batch_size` = number of render groups of the step (trainer.py:965)."""
+        self._stats_sink = (running_stats, int(batch_size), bool(update_max_radii))  # the dict itself: control steps
+        #                                                                  replace its tensors when N changes
+
+    def detach_control_stats(self):
+        self._stats_sink = None
+
+    def _sink_for(self, N: int):
+        if self._stats_sink is None or not torch.is_grad_enabled():
+            return None
+        stats, batch_size, upd = self._stats_sink
+        if stats["vis_count"].shape[0] != N:
+            return None
+        return dict(stats, batch_size=batch_size, update_max_radii=upd)
 
     num_gaussians = property(lambda self: self.num_bg_gaussians + self.num_fg_gaussians)
     num_bg_gaussians = property(lambda self: self.bg.num_gaussians if self.bg is not None else 0)
@@ -282,7 +308,8 @@ class SceneModel(nn.Module):
             P["means"], P["quats"], P["scales"], P["opacities"], colors_override, n_sigmoid, coefs,
             self.motion_bases.params["rots"] if G > 0 else None, self.motion_bases.params["transls"] if G > 0 else None,
             times_s if G > 0 else None, RTs_s, w2cs[0], Ks[0], W, H, background=bg_color[0], return_depth=return_depth,
-            policy=None, blend=True)
+            policy=None, blend=True,
+            control_stats=self._sink_for(N) if (which == "all" and filter_mask is None) else None)
         blended = res["blended"][None]  # [1,H,W,D']
         renders = res["renders"]
 

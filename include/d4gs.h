@@ -138,6 +138,16 @@ typedef struct D4gsRasterGrads {
   float *v_depths;              /* [S,N]   (zeros when depth_mode == 0) */
   float *v_opac_act;            /* [N]     summed over S */
   float *v_ctab;                /* [N,DP]  summed over S */
+  /* SURVEY 8f-1, fused: when stats_grad_norm_acc != NULL the gather epilogue also does the accumulation loop of
+   * Trainer._prepare_control_step (flow3d/trainer.py:967-989) for this render - per visible instance (radii > 0), in
+   * sub-sample order: grad_norm_acc[g] += |v_means2d * (W/2, H/2) * stats_batch_size * S|, vis_count[g] += 1, and, only
+   * if stats_update_max_radii (the reference's index_put result is discarded, so upstream never updates it),
+   * max_radii[g] = max(max_radii[g], radius / max(W, H)).  Same arithmetic and order as d4gs_control_stats. */
+  float *stats_grad_norm_acc;   /* [N] or NULL */
+  int64_t *stats_vis_count;     /* [N] */
+  float *stats_max_radii;       /* [N] */
+  int32_t stats_batch_size;
+  int32_t stats_update_max_radii;
 } D4gsRasterGrads;
 
 /* leaf gradients produced by d4gs_project_bwd (all overwritten, not accumulated) */
@@ -216,6 +226,20 @@ int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad /* [S,N,2] */
                        int32_t width, int32_t height, int32_t batch_size, float *grad_norm_acc /* [N] */,
                        int64_t *vis_count /* [N] */, float *max_radii /* [N] */, int32_t update_max_radii,
                        void *stream);
+
+/* SURVEY 8f-1, control steps: the row surgery of GaussianParams.densify_params / cull_params (flow3d/params.py:86-118)
+ * and of dup_in_optim / remove_from_optim (flow3d/trainer.py:1199-1236) as stream compaction.
+ * d4gs_control_plan: flags [N] (uint8) -> src_map (capacity 3N for a densify plan, N for a cull plan) in the reference's
+ * row order - rows with split == 0, then rows with dup != 0, then the rows with split != 0 TWICE (x[split].repeat(2));
+ * with dup == NULL the first flag array is a cull mask and the plan keeps the rows whose flag is 0.
+ * counts [4] (device) = {n_keep, n_dup, n_split, n_out}.  d4gs_gather_rows: out[i,:] = in[src_map[i],:] for one tensor
+ * of `row_floats` 32-bit words per row; rows >= zero_from are zero-filled (new Adam moments: zero_from = n_keep), rows
+ * >= add_from get `add` added (split halves of `scales`: add_from = n_keep + n_dup, add = -log 1.6); pass INT64_MAX
+ * to disable either. */
+int d4gs_control_plan(int32_t N, const uint8_t *split_or_cull, const uint8_t *dup, int32_t *src_map, int32_t *counts,
+                      void *stream);
+int d4gs_gather_rows(const int32_t *src_map, int64_t n_out, int32_t row_floats, const float *in, float *out,
+                     int64_t zero_from, int64_t add_from, float add, void *stream);
 
 /* a12 camera path: the generator of `RTs [S,3,4]` / `times [S]` that feed d4gs_project_fwd.
  * Replaces the eager chain of MoveModel.forward_start_end_mid (flow3d/models/move_model.py:138-166):

@@ -149,6 +149,33 @@ def test_any_channel_layout_matches_the_reference_policy(has_bg, B, depth, mask)
         check(case, name, got_p.grad.cpu(), ref_p.grad, 1e-4, GRAD_FLIP_FRAC)
 
 
+def test_render_from_a_loaded_reference_checkpoint(tmp_path):
+    """save the reference Trainer's checkpoint dict, load it back, render on the device: the images equal
+    the original model's once its exposure half-widths are at 0.5 too (the loader resets `time_params`)."""
+    from deblur4dgs_amd.checkpoint import load_reference_checkpoint, reference_checkpoint_dict
+
+    dev = torch.device("cuda:0")
+    N, G, K, W, H = 900, 500, 4, 64, 48
+    model, sc = _build(N, G, K, W, H, 29, dev)  # non-default time_params, non-zero heads
+    path = tmp_path / "ckpt.pt"
+    torch.save(reference_checkpoint_dict(model, global_step=10), path)
+    loaded, meta = load_reference_checkpoint(str(path), device=dev)
+    assert meta["global_step"] == 10 and loaded.num_fg_gaussians == G and loaded.num_bg_gaussians == N - G
+    args = (3.0, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H))
+    with torch.no_grad():
+        a = loaded.render(*args, return_depth=True, mode="blury")
+        b = model.render(*args, return_depth=True, mode="blury")
+        assert not torch.equal(a["img"], b["img"])            # 0.6 vs the reset 0.5 exposure half-width
+        model.move_model.time_params.fill_(0.5)
+        c = model.render(*args, return_depth=True, mode="blury")
+    for k in ("img", "depth", "acc", "RTs", "exposure_imgs"):
+        assert torch.equal(a[k], c[k]), k
+    # and it trains: gradients reach the loaded leaves
+    out = loaded.render(*args, return_depth=True, mode="blury")
+    out["img"].square().sum().backward()
+    assert loaded.fg.params["means"].grad.abs().sum() > 0 and loaded.move_model.time_params.grad is not None
+
+
 def test_render_view_and_inference_mode():
     from deblur4dgs_amd.scene_model import render_view
 
@@ -186,6 +213,24 @@ def test_control_stats_match_reference_accumulation():
     assert torch.equal(stats["vis_count"].cpu(), ref["vis_count"])
     assert torch.equal(stats["max_radii"].cpu(), ref["max_radii"])  # reference quirk: never updated (index_put)
     assert torch.allclose(stats["xys_grad_norm_acc"].cpu(), ref["xys_grad_norm_acc"], rtol=1e-5, atol=1e-7)
+    # fused: the same numbers out of the raster backward's gather epilogue (no torch.cat, no extra pass), bit for bit
+    for B in (None, 6):  # B = 6 track frames -> 23 channels -> chunked composite -> statistics on the summed gradient
+        fused = {"xys_grad_norm_acc": torch.rand(N, device=dev), "vis_count": torch.randint(0, 5, (N,), device=dev),
+                 "max_radii": torch.rand(N, device=dev) * 0.05}
+        sep = {k: v.clone() for k, v in fused.items()}
+        kw = {} if B is None else dict(target_ts=torch.linspace(0.5, 6.0, B).to(dev),
+                                       target_w2cs=torch.eye(4, device=dev).expand(B, 4, 4).contiguous())
+        for it in range(2):
+            model.attach_control_stats(fused, batch_size=3)
+            out = model.render(3.0, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H), return_depth=True,
+                               mode="blury", **kw)
+            (out["img"].square().sum() + (out["tracks_3d"].sum() if B else 0.0)).backward()
+            model.detach_control_stats()
+            accumulate_from_model(sep, model, batch_size=3)
+        torch.cuda.synchronize()
+        for k in fused:
+            assert torch.equal(fused[k], sep[k]), (k, B)
+        assert int((fused["vis_count"] - 0).sum()) > 0
     # the intended semantics are available behind a flag
     before = stats["max_radii"].clone()
     accumulate_from_model(stats, model, batch_size=2, update_max_radii=True)

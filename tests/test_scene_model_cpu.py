@@ -46,3 +46,35 @@ def test_render_on_cpu_fails_loudly():
     m, sc = _model()
     with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):
         m.render(2, sc["viewmat"][None], sc["K"][None], (32, 32))
+
+
+def test_reference_trainer_checkpoint_loads_with_its_quirks(tmp_path):
+    """flow3d/trainer.py:126-170: scene from ckpt["model"], MoveModel weights from ckpt["move_model"], `time_params`
+    dropped (shape[0] == 1 != num_fg) and therefore back at its 0.5 initialisation; global_step / epoch returned."""
+    from deblur4dgs_amd.checkpoint import load_reference_checkpoint, reference_checkpoint_dict
+
+    m, _ = _model()
+    with torch.no_grad():
+        for p in m.move_model.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+        m.move_model.time_params.copy_(torch.tensor([[0.5, 0.3, 0.45, 0.6, 0.2, 0.5, 0.7, 0.5]]))
+    opt = {"fg.params.means": torch.optim.Adam([m.fg.params["means"]], lr=1e-3)}
+    ck = reference_checkpoint_dict(m, optimizers=opt, global_step=1234, epoch=7)
+    assert set(ck) == {"model", "optimizers", "schedulers", "global_step", "epoch", "move_model"}
+    assert "move_model.RT_main.0.weight" in ck["model"]  # the submodule's entries ride in the model dict too (ignored on load)
+    path = tmp_path / "last.ckpt"
+    torch.save(ck, path)
+    m2, meta = load_reference_checkpoint(str(path))
+    assert meta["global_step"] == 1234 and meta["epoch"] == 7 and "fg.params.means" in meta["optimizers"]
+    for k in ("fg.params.means", "fg.params.motion_coefs", "bg.params.scales", "motion_bases.params.rots", "Ks", "w2cs"):
+        assert torch.equal(m2.state_dict()[k], m.state_dict()[k]), k
+    for k, v in m.move_model.state_dict().items():
+        if k == "time_params":
+            assert torch.equal(m2.move_model.time_params, torch.full((1, 8), 0.5))  # the reset quirk (trainer.py:156-157)
+        else:
+            assert torch.equal(m2.move_model.state_dict()[k], v), k
+    # a checkpoint without the separate "move_model" entry keeps a freshly initialised MoveModel (zero heads)
+    m3, _ = load_reference_checkpoint({"model": ck["model"]})
+    assert float(m3.move_model.RT_head0[-1].weight.abs().sum()) == 0.0
+    with pytest.raises(KeyError):
+        load_reference_checkpoint({"state_dict": {}})
