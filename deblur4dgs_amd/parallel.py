@@ -5,10 +5,17 @@ constrained only by "the sharded result equals the single-GPU result":
 
 * exposure sharding (BASELINE config 4): the S sub-samples of ONE blurry frame are independent given replicated
   leaf parameters (flow3d/scene_model.py:323-384); rank r renders {s : s % P == r}.  The only coupling is the blend
-  (scene_model.py:386-397):   SUM all-reduce of [H,W,D'+1] (colours + alpha)  ->  mean,
-                              MAX all-reduce of the max/min-policy channels (min packed as -x),
-  and in the backward one MIN all-reduce of the winning sub-sample index for those channels, then ONE flat SUM
-  all-reduce of all leaf gradients (replicated params -> data-parallel gradient sum).
+  (scene_model.py:386-397).  Default (`GatherBlendFn`, needs S % P == 0): ONE all-gather of the ranks' sub-sample
+  images [S/P,H,W,D'+1] puts the whole S-stack on every rank, which then runs the same HIP blend kernels as the
+  single-GPU path (`k_blend_fwd/bwd`) - the blended image is BITWISE the single-GPU image (same summation order),
+  the max / min channels and their winners need no extra collective, the backward keeps the slice of the stack
+  gradient that belongs to the rank's own sub-samples (the loss is evaluated redundantly, so no reduction), and the
+  per-sub-sample stack the trainer's pairwise exposure losses read (flow3d/trainer.py:599-618) is there for free.
+  Ragged S falls back to `ShardedBlendFn`: SUM all-reduce of [H,W,D'+1] + MAX all-reduce of the policy channels
+  (min packed as -x) forward, MIN all-reduce of the winning sub-sample backward.
+  Then the leaf gradients: ONE flat buffer, all-reduced in two pieces - the per-Gaussian leaves (24 MB on cfg2) as
+  soon as the projection backward has written them (async on RCCL's stream, overlapping the rest of autograd: the
+  MoveModel backward and the host-side launch work), the small shared leaves at the end.
 * view sharding: every rank renders a full frame of its own camera view; only the flat gradient all-reduce remains.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): messages here are 2.4-24 MB, i.e. latency/launch-bound, so
@@ -87,29 +94,117 @@ class ShardedBlendFn(torch.autograd.Function):
         return v_r, v_a, None, None, None, None
 
 
+class GatherBlendFn(torch.autograd.Function):
+    """All-gather the ranks' sub-sample images, then blend the full stack locally with `blend_fn` (exposure.BlendFn:
+    the HIP kernels; the gloo CPU tests inject a torch restatement).  Needs S % world == 0."""
+
+    @staticmethod
+    def forward(ctx, renders, alphas, S, policy, group, blend_fn):
+        Sl, H, W, Cn = renders.shape
+        P = S // Sl
+        assert Sl * P == S and P == dist.get_world_size(group), "GatherBlendFn needs S % world_size == 0"
+        packed = torch.cat([renders, alphas[..., None]], -1).contiguous()  # [Sl,H,W,C+1]
+        full = torch.empty(P * Sl, H, W, Cn + 1, dtype=renders.dtype, device=renders.device)
+        dist.all_gather_into_tensor(full, packed, group=group)  # rank-major concatenation along dim 0
+        # rank r holds s = j * P + r (owned_subsamples): [P,Sl] -> s-major
+        stack = full.view(P, Sl, H, W, Cn + 1).transpose(0, 1).reshape(S, H, W, Cn + 1)
+        with torch.enable_grad():
+            st_r = stack[..., :Cn].contiguous().requires_grad_()
+            st_a = stack[..., Cn].contiguous().requires_grad_()
+            out, acc = blend_fn(st_r, st_a, policy)
+        ctx.save_for_backward(st_r, st_a, out, acc)
+        ctx.meta = (S, Sl, P, dist.get_rank(group))
+        return out.detach(), acc.detach(), stack.detach()
+
+    @staticmethod
+    def backward(ctx, v_out, v_acc, v_stack):
+        st_r, st_a, out, acc = ctx.saved_tensors
+        S, Sl, P, rank = ctx.meta
+        outs, grads = [], []
+        for o, g in ((out, v_out), (acc, v_acc)):
+            if g is not None:
+                outs.append(o)
+                grads.append(g)
+        g_r, g_a = torch.autograd.grad(outs, [st_r, st_a], grads, allow_unused=True) if outs else (None, None)
+        g_r = torch.zeros_like(st_r) if g_r is None else g_r
+        g_a = torch.zeros_like(st_a) if g_a is None else g_a
+        if v_stack is not None:  # losses on the per-sub-sample images (trainer.py:599-618)
+            g_r = g_r + v_stack[..., :-1]
+            g_a = g_a + v_stack[..., -1]
+        own = slice(rank, S, P)  # this rank's sub-samples; the loss is replicated, so their gradient is local
+        return g_r[own].contiguous(), g_a[own].contiguous(), None, None, None, None
+
+
+PER_GAUSSIAN = ("means", "quats", "scales", "opacities", "colors", "motion_coefs")
+
+
 class FlatGradAllReduce:
-    """All leaf gradients in ONE flat buffer -> one SUM all-reduce (latency-bound sizes; see module docstring)."""
+    """All leaf gradients in ONE flat buffer (latency-bound sizes; see module docstring), laid out
+    [per-Gaussian leaves | shared leaves].  `reduce()` = one SUM all-reduce per piece; with `arm()` before the
+    backward, the per-Gaussian piece is launched asynchronously the moment autograd has accumulated the last
+    per-Gaussian leaf (they are written together by d4gs_project_bwd), so it travels while the rest of the backward
+    (MoveModel, host launch work) runs; `reduce()` then only waits for it and reduces the small shared piece."""
 
     def __init__(self, leaves: dict, group=None):
-        self.names = list(leaves)
+        self.names = [k for k in leaves if k in PER_GAUSSIAN] + [k for k in leaves if k not in PER_GAUSSIAN]
         self.group = group
         n = sum(leaves[k].numel() for k in self.names)
         ref = leaves[self.names[0]]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.views, off = {}, 0
+        self.n_big = 0
         for k in self.names:
             m = leaves[k].numel()
             self.views[k] = self.flat[off:off + m].view_as(leaves[k])
             off += m
+            if k in PER_GAUSSIAN:
+                self.n_big = off
+        self._work = None
+        self._hooks = []
+        self._pending = set()
 
-    def reduce(self, leaves: dict, average: bool = False):
-        for k in self.names:
+    def _fill(self, leaves, names):
+        for k in names:
             g = leaves[k].grad
             if g is None:
                 self.views[k].zero_()
             elif g.data_ptr() != self.views[k].data_ptr():  # already written in place when the views were passed to
                 self.views[k].copy_(g)                      # the renderer as its `grad_arena`
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def arm(self, leaves: dict):
+        """Call before backward(): launch the per-Gaussian all-reduce from autograd's post-accumulate hooks."""
+        self.disarm()
+        big = [k for k in self.names if k in PER_GAUSSIAN]
+        if not big or not hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            return
+        self._pending = set(big)
+
+        def make(k):
+            def hook(_p):
+                self._pending.discard(k)
+                if not self._pending and self._work is None:
+                    self._fill(leaves, big)
+                    self._work = dist.all_reduce(self.flat[: self.n_big], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return hook
+
+        self._hooks = [leaves[k].register_post_accumulate_grad_hook(make(k)) for k in big]
+
+    def disarm(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._work, self._pending = [], None, set()
+
+    def reduce(self, leaves: dict, average: bool = False):
+        small = [k for k in self.names if k not in PER_GAUSSIAN]
+        if self._work is not None:  # the big piece is already in flight
+            self._fill(leaves, small)
+            if self.n_big < self.flat.numel():
+                dist.all_reduce(self.flat[self.n_big:], op=dist.ReduceOp.SUM, group=self.group)
+            self._work.wait()
+        else:
+            self._fill(leaves, self.names)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.disarm()
         if average:
             self.flat /= dist.get_world_size(self.group)
         for k in self.names:
@@ -144,6 +239,7 @@ class ShardedExposure:
             loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
             # data-parallel mean of the per-view gradients: the 1 / world factor rides on the loss, so the SUM
             # all-reduce needs no 24 MB division pass afterwards
+            self.reducer.arm(leaves)
             (loss * (1.0 / self.world)).backward()
             self.reducer.reduce(leaves)
             return res["state"]
@@ -155,8 +251,15 @@ class ShardedExposure:
                               leaves["viewmat"], Kmat, W, H, background=background, return_depth=True, blend=False,
                               grad_arena=self.reducer.views)
         pol = reference_policy(res["renders"].shape[-1])
-        blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), own, S, pol, self.group)
+        if S % self.world == 0:  # one all-gather, then the single-GPU blend kernels on the full stack (bitwise equal)
+            from .exposure import BlendFn
+
+            blended, acc, _stack = GatherBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), S, pol, self.group,
+                                                       BlendFn.apply)
+        else:
+            blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), own, S, pol, self.group)
         loss = torch.dot(blended.reshape(-1), wimg.reshape(-1)) + torch.dot(acc.reshape(-1), wacc.reshape(-1))
+        self.reducer.arm(leaves)
         loss.backward()
         self.reducer.reduce(leaves)
         return res["state"]

@@ -85,6 +85,93 @@ def test_sharded_blend_matches_reference_blend(world, S, C):
         torch.testing.assert_close(gscale, scale.grad, rtol=0, atol=1e-11)  # all-reduced leaf gradient
 
 
+def _oracle_blend(renders, alphas, policy):
+    """(stack [S,H,W,C], alphas [S,H,W], policy) -> (out [H,W,C], acc [H,W]) through oracle/scene.py's literal
+    restatement of scene_model.py:386-397 (the policy IS the reference's: channel 3 max, 16 min)."""
+    from oracle import scene as oscene
+
+    S = renders.shape[0]
+    blended, acc, _ = oscene.blend_exposure([renders[s][None] for s in range(S)], [alphas[s][None] for s in range(S)],
+                                            single=(S == 1))
+    return blended[0], acc[0]
+
+
+def _gather_worker(rank, world, port, S, C, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deblur4dgs_amd.exposure import reference_policy
+    from deblur4dgs_amd.parallel import FlatGradAllReduce, GatherBlendFn, owned_subsamples
+
+    g = torch.Generator().manual_seed(seed)
+    H, W = 6, 5
+    renders = torch.rand(S, H, W, C, generator=g, dtype=torch.float64)
+    renders[:, 0, 0, 3] = 0.0
+    renders[S - 1, 1, 1, 3] = 5.0
+    alphas = torch.rand(S, H, W, generator=g, dtype=torch.float64)
+    wb = torch.randn(H, W, C, generator=g, dtype=torch.float64)
+    wa = torch.randn(H, W, generator=g, dtype=torch.float64)
+    ws = torch.randn(S, H, W, C + 1, generator=g, dtype=torch.float64)  # a loss on the per-sub-sample stack too
+    scale = torch.ones(S, dtype=torch.float64, requires_grad=True)
+    means = torch.ones(3, dtype=torch.float64, requires_grad=True)      # a "per-Gaussian" leaf: early async all-reduce
+    own = owned_subsamples(S, world, rank)
+    loc = renders[own] * scale[own].view(-1, 1, 1, 1) * means.sum() / 3.0
+    loc.retain_grad()
+    la = alphas[own].clone().requires_grad_()
+    out, acc, stack = GatherBlendFn.apply(loc, la, S, reference_policy(C), None, _oracle_blend)
+    leaves = {"scale": scale, "means": means}
+    red = FlatGradAllReduce(leaves)
+    red.arm(leaves)
+    ((out * wb).sum() + (acc * wa).sum() + (stack * ws).sum()).backward()
+    armed = red._work is not None
+    red.reduce(leaves)
+    q.put((rank, own, out.detach(), acc.detach(), stack.detach(), loc.grad.clone(), la.grad.clone(), scale.grad.clone(),
+           means.grad.clone(), armed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,S,C", [(2, 8, 17), (2, 2, 5), (3, 6, 4), (2, 4, 20)])
+def test_gather_blend_equals_the_single_process_blend_bitwise(world, S, C):
+    """The default exposure-sharded blend: one all-gather, then the single-process blend on the full stack - outputs
+    and local gradients are BITWISE those of the single-process run (same summation order), and the flat gradient
+    reducer's early asynchronous piece fires from autograd's hooks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, S, C, 13, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    g = torch.Generator().manual_seed(13)
+    H, W = 6, 5
+    renders = torch.rand(S, H, W, C, generator=g, dtype=torch.float64)
+    renders[:, 0, 0, 3] = 0.0
+    renders[S - 1, 1, 1, 3] = 5.0
+    alphas = torch.rand(S, H, W, generator=g, dtype=torch.float64)
+    wb = torch.randn(H, W, C, generator=g, dtype=torch.float64)
+    wa = torch.randn(H, W, generator=g, dtype=torch.float64)
+    ws = torch.randn(S, H, W, C + 1, generator=g, dtype=torch.float64)
+    scale = torch.ones(S, dtype=torch.float64, requires_grad=True)
+    means = torch.ones(3, dtype=torch.float64, requires_grad=True)
+    r = renders * scale.view(-1, 1, 1, 1) * means.sum() / 3.0
+    r.retain_grad()
+    a = alphas.clone().requires_grad_()
+    blended, acc = _oracle_blend(r, a, None)
+    stack = torch.cat([r, a[..., None]], -1)
+    ((blended * wb).sum() + (acc * wa).sum() + (stack * ws).sum()).backward()
+    for rank, own, out, acc_r, st, gr, ga, gscale, gmeans, armed in res:
+        assert own == list(range(rank, S, world)) and armed
+        assert torch.equal(out, blended.detach()) and torch.equal(acc_r, acc.detach()) and torch.equal(st, stack.detach())
+        assert torch.equal(gr, r.grad[own]) and torch.equal(ga, a.grad[own])
+        # replicated loss, every rank differentiates its own sub-samples: the all-reduced leaf gradients are the totals
+        torch.testing.assert_close(gscale, scale.grad, rtol=0, atol=1e-12)
+        torch.testing.assert_close(gmeans, means.grad, rtol=1e-12, atol=1e-9)
+
+
 def test_owned_subsamples_partition():
     from deblur4dgs_amd.parallel import owned_subsamples
 
