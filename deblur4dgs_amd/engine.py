@@ -43,6 +43,11 @@ class RenderCfg:
     radius_clip: float = 0.0
     exact_cull: bool = True
     optimistic_sizes: bool = True  # size the intersection lists from the previous call's count, verify afterwards
+    deferred_size_check: bool = False  # never wait for the device-side count in this call: size the lists from the
+    #                                  previous call's count (+25 %), let every kernel check it on the device, and look
+    #                                  at the count at the NEXT call of this shape (or `check_deferred()`); an overflow
+    #                                  raises there, like an asynchronous device error.  No host stall, and the whole
+    #                                  render (forward + backward) can be captured in a HIP graph after one warm-up call.
     grad_arena: dict | None = None  # optional {"means": tensor, ...}: leaf gradients are written THERE (e.g. views of
     #                                  a flat all-reduce buffer) instead of fresh tensors; shapes / dtype must match
     control_stats: dict | None = None  # optional densification-statistics sink, updated by the backward's gather epilogue
@@ -129,6 +134,37 @@ def _guess_put(key, val):
         _SIZE_GUESS.move_to_end(key)
         while len(_SIZE_GUESS) > _SIZE_GUESS_MAX:
             _SIZE_GUESS.popitem(last=False)
+
+
+_DEFERRED: dict = {}  # size key -> (pinned int64[2], event, capacity, max-tile hint) of the last unchecked render
+
+
+def _deferred_poll(key, block: bool = False):
+    """Look at the count of the previous deferred render of this shape, if it has arrived.  -> (n, max_tile) | None."""
+    with _SIZE_LOCK:
+        rec = _DEFERRED.get(key)
+    if rec is None:
+        return None
+    host_n, ev, cap, hint = rec
+    if not block and not ev.query():
+        return None
+    ev.synchronize()
+    with _SIZE_LOCK:
+        _DEFERRED.pop(key, None)
+    n, max_tile = host_n.tolist()
+    _guess_put(key, (n + n // 4 + 4096, 2048 if 3 * max_tile <= 2 * 2048 else 16384 if 3 * max_tile <= 2 * 16384 else 0))
+    if n > cap or (hint > 0 and max_tile > hint):
+        raise RuntimeError(f"deblur4dgs_amd: a render with deferred_size_check needed {n} intersections (longest tile "
+                           f"list {max_tile}) but its lists were sized for {cap} (class {hint}): that render's output "
+                           "was INVALID (its kernels skipped the work).  Re-run the step; the size guess is updated.")
+    return n, max_tile
+
+
+def check_deferred():
+    """Wait for and verify every outstanding deferred size check (call once per training step, e.g. where the loss is
+    read back anyway).  Raises RuntimeError if a render overflowed its intersection lists."""
+    for key in list(_DEFERRED):
+        _deferred_poll(key, block=True)
 
 
 def _pinned_counts(dev):
@@ -299,13 +335,33 @@ class RasterFn(torch.autograd.Function):
             L.check(lib.d4gs_bin_sort(C.byref(dims), C.byref(pout), C.byref(isect), _stream()), "d4gs_bin_sort")
             raster(cap, max_hint)
 
+        key = _size_key(dev, S, cfg.N, W, H)
+        guess = None
+        if not st.binned and cfg.deferred_size_check:
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
+                _deferred_poll(key)  # raises if the previous render of this shape overflowed
+            guess = _guess_get(key)
         if st.binned:
             raster(st.n_isect, st.max_tile)
+        elif guess is not None:
+            # deferred check: launch at the guessed capacity, never wait.  The count travels to pinned memory behind
+            # the launches and is looked at by the next call (not under stream capture: a graph replays this shape).
+            launch(*guess)
+            if not capturing:
+                host_n = torch.empty(2, dtype=torch.int64).pin_memory()
+                host_n.copy_(st.proj_out["n_isect"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                with _SIZE_LOCK:
+                    _DEFERRED[key] = (host_n, ev, guess[0], guess[1])
+            st.n_isect, st.max_tile, st.binned = guess[0], guess[1], True
+            st.raster = rst
+            _SIZE_STATS["calls"] += 1
         else:
             # The list sizes live on the device.  Read them back through pinned memory; when a previous call of the same
             # shape left a guess, launch binning + rasterization FIRST (sized by the guess, checked on the device) and
             # wait for the counts afterwards, so the GPU never idles on the host round trip (70 us per render).
-            key = _size_key(dev, S, cfg.N, W, H)
             host_n = _pinned_counts(dev)
             host_n.copy_(st.proj_out["n_isect"], non_blocking=True)
             ev = torch.cuda.Event()

@@ -83,6 +83,7 @@ def render_exposure(
     exact_cull: bool = True,
     grad_arena: dict | None = None,
     control_stats: dict | None = None,
+    deferred_size_check: bool = False,
 ):
     """-> dict(renders [S,H,W,D'], alphas [S,H,W,1], blended [H,W,D'] | None, acc [H,W] | None,
                means2d [S,N,2], radii [S,N], state)."""
@@ -95,7 +96,8 @@ def render_exposure(
     cfg = RenderCfg(N=N, G=G, K=0 if G == 0 else rots.shape[0], T=0 if G == 0 else rots.shape[1], S=S,
                     D=colors.shape[-1], width=width, height=height,
                     depth_mode=L.DEPTH_ED if return_depth else L.DEPTH_NONE, flags=flags, n_sigmoid=n_sigmoid,
-                    exact_cull=exact_cull, grad_arena=grad_arena, control_stats=control_stats)
+                    exact_cull=exact_cull, grad_arena=grad_arena, control_stats=control_stats,
+                    deferred_size_check=deferred_size_check)
     rc, ra, means2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors, motion_coefs, rots,
                                                   transls, times, RTs, w2c, Kmat, background)
     out = dict(renders=rc, alphas=ra, means2d=means2d, radii=radii, state=st, blended=None, acc=None)
