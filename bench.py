@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md section 3's whole plan (cfg1 x 20 iterations, cfg2 x 3, torch and scalar C); minutes")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step (render forward + backward, deferred size check) in a HIP graph and time its "
+                         "replays; single GPU only")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL code path with world_size 1")
     return ap.parse_args()
 
@@ -284,7 +287,7 @@ def main():
         raise SystemExit(f"--shard exposure needs world_size <= S ({world} > {S})")
     bg = torch.ones(channels, device=dev)
     lib = L.lib()
-    prof = not args.no_profile
+    prof = not args.no_profile and not args.graph  # HIP events cannot bracket kernels inside a replayed graph
 
     def sync():
         if use_dist:
@@ -328,6 +331,40 @@ def main():
         for _ in range(warmup):
             step()
         sync()
+        if args.graph and sharder is None:  # same kernels, same arithmetic; one hipGraphLaunch per step
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            kw_def = dict(deferred_size_check=True)
+
+            def gstep():
+                for v in leaves.values():
+                    v.grad = None
+                res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
+                                      leaves["colors"], 3, leaves.get("motion_coefs"), leaves.get("rots"),
+                                      leaves.get("transls"), leaves.get("times"), leaves["RTs"], leaves["viewmat"], d["K"],
+                                      W, H, background=bg, return_depth=True, **kw_def)
+                loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
+                loss.backward()
+                return res["state"]
+
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    gstep()
+            torch.cuda.current_stream().wait_stream(side)
+            for v in leaves.values():
+                v.grad = None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gstate = gstep()
+            real_state = last["st"]
+
+            def step():  # noqa: F811
+                graph.replay()
+                last["st"] = real_state  # exact list sizes of the same scene (the captured state holds capacities)
+
+            for _ in range(3):
+                step()
+            sync()
         if profile:
             lib.d4gs_profile_enable(2)  # HIP events around the rasterization kernels only: timing EVERY kernel costs two
         t0 = time.perf_counter()      # stream events per launch, ~0.12 ms of a 1.6 ms frame
@@ -370,6 +407,8 @@ def main():
                     if not views_primary else f"views sharded x{world} (data parallel), RCCL gradient all-reduce")},
         "instances_per_s": value * S,
     }
+    if args.graph:
+        out["config"]["launch"] = "one HIP graph per step (render forward + backward captured, deferred size check)"
     if world > 1 and not views_primary:  # secondary: data-parallel over camera views (weak scaling), same protocol
         dt_v, _, _, _, _ = measure("views", args.steps, args.warmup, False)
         out["views_weak_scaling"] = {"value": world * N / (dt_v / args.steps), "unit": "Gaussians/s", "scaling": "weak",

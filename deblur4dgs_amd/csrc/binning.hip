@@ -230,7 +230,7 @@ struct SortArgs {
   int64_t n_cap, max_hint;
 };
 
-__global__ void __launch_bounds__(256) k_tile_sort(const SortArgs a) {
+__global__ void __launch_bounds__(1024) k_tile_sort(const SortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
   if (over_capacity(a.n_dev, a.n_cap, a.max_hint)) return;
   const int t = blockIdx.x;
@@ -288,18 +288,21 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   int rc = d4gs_check_launch("k_emit");
   if (rc) return rc;
   const int n_tiles = dims->S * e.tw * e.th;
-  // Three size classes, one launch each (a workgroup exits at once if its list is not in the class): short lists
-  // sort with 16 KB of LDS (8+ workgroups / CU), long ones with up to 128 KB, anything longer in global memory.
+  // Size classes, one launch each (a workgroup exits at once if its list is not in the class): the LDS a workgroup
+  // reserves and its width follow the list length - 16 KB / 256 lanes up to 2048 keys (8+ workgroups per CU) ...
+  // 128 KB / 1024 lanes up to 16384 keys, anything longer in global memory.  (Round 1 had only the 16 KB and 128 KB
+  // classes: a scene whose lists run to ~4 k keys sorted them one workgroup of 4 waves per CU - 1.54 ms on cfg2 with
+  // 4x larger splats.)
   // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
   (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-  const int classes[3][2] = {{0, 2048}, {2048, 16384}, {16384, -1}};
-  for (int c = 0; c < 3; c++) {
+  const int classes[6][3] = {{0, 2048, 256}, {2048, 4096, 512}, {4096, 8192, 1024}, {8192, 16384, 1024}, {16384, -1, 1024}};
+  for (int c = 0; c < 5; c++) {
     const int64_t longest = isect->max_tile_count > 0 ? isect->max_tile_count : isect->n_isect;
     if (c > 0 && longest <= classes[c][0]) break;  // no list is that long
     SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
                classes[c][0], classes[c][1], proj->n_isect, isect->n_isect, isect->max_tile_count};
     const size_t lds = classes[c][1] > 0 ? (size_t)classes[c][1] * 8 : 0;
-    D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(256), lds, stream, s);
+    D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(classes[c][2]), lds, stream, s);
   }
   return d4gs_check_launch("k_tile_sort");
 }

@@ -115,6 +115,15 @@ _SIZE_STATS = {"calls": 0, "relaunched": 0}
 _PINNED: dict = {}
 
 
+def _sort_class(max_tile: int) -> int:
+    """Upper bound on the longest tile list handed to d4gs_bin_sort (with 50 % headroom), rounded to a sort size class;
+    0 = unknown (every class is launched)."""
+    for c in (2048, 4096, 8192, 16384):
+        if 3 * max_tile <= 2 * c:
+            return c
+    return 0
+
+
 def _size_key(dev, S, N, W, H):
     shift = max(N.bit_length() - 2, 0)
     return (dev.index, S, W, H, (N >> shift) << shift)
@@ -152,7 +161,7 @@ def _deferred_poll(key, block: bool = False):
     with _SIZE_LOCK:
         _DEFERRED.pop(key, None)
     n, max_tile = host_n.tolist()
-    _guess_put(key, (n + n // 4 + 4096, 2048 if 3 * max_tile <= 2 * 2048 else 16384 if 3 * max_tile <= 2 * 16384 else 0))
+    _guess_put(key, (n + n // 4 + 4096, _sort_class(max_tile)))
     if n > cap or (hint > 0 and max_tile > hint):
         raise RuntimeError(f"deblur4dgs_amd: a render with deferred_size_check needed {n} intersections (longest tile "
                            f"list {max_tile}) but its lists were sized for {cap} (class {hint}): that render's output "
@@ -377,7 +386,7 @@ class RasterFn(torch.autograd.Function):
                 launch(n, max_tile)
             _SIZE_STATS["calls"] += 1
             _guess_put(key, (n + n // 4 + 4096,
-                             2048 if 3 * max_tile <= 2 * 2048 else 16384 if 3 * max_tile <= 2 * 16384 else 0))
+                             _sort_class(max_tile)))
             st.n_isect, st.max_tile, st.binned = n, max_tile, True
             st.raster = rst
         ctx.st, ctx.cfg, ctx.rst, ctx.ctab = st, cfg, rst, ctab

@@ -1,16 +1,31 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc_fetch.txt + pmc_write.txt (scripts/pmc_run.sh) -> profiles/pmc_traffic.json (KB per launch)."""
+"""gpurun_out/pmc_<tag>_{fetch,write,sq}.txt (scripts/pmc_run.sh via scripts/profile_round.sh) ->
+profiles/pmc_traffic.json (FETCH_SIZE / WRITE_SIZE, KB per launch, per kernel) and profiles/<round>_pmc_sq_<cfg>.json
+(SQ / GRBM counters per launch).   usage: pmc_to_json.py <tag> <round> [cfg]"""
 import json, re, sys
-out = {}
-for path, ctr in (("gpurun_out/pmc_fetch.txt", "FETCH_SIZE"), ("gpurun_out/pmc_write.txt", "WRITE_SIZE")):
+
+tag, rnd = sys.argv[1], sys.argv[2]
+cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
+
+
+def parse(path):
+    out = {}
     for ln in open(path):
         m = re.match(r"(.{42}) (\S+)\s+avg\s+([\d.]+)\s+n\s+(\d+)", ln)
-        if not m or m.group(2) != ctr:
+        if not m:
             continue
         k = m.group(1).strip().replace("void ", "").split("<")[0].split("(")[0]
-        out.setdefault(k, {})[ctr] = round(float(m.group(3)), 1)
-tag = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-doc = {tag: {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only), "
-                       "profiles/r01_j_pmc_hbm_cfg2.txt; KB per launch", "kernels": out}}
+        out.setdefault(k, {})[m.group(2)] = round(float(m.group(3)), 1)
+    return out
+
+
+traffic = {}
+for part in ("fetch", "write"):
+    for k, v in parse(f"gpurun_out/pmc_{tag}_{part}.txt").items():
+        traffic.setdefault(k, {}).update(v)
+doc = {cfg: {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only), "
+                       f"profiles/{rnd}_pmc_fetch_{cfg}.txt / {rnd}_pmc_write_{cfg}.txt; KB per launch",
+             "kernels": {k: v for k, v in traffic.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}}}
 json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
-print(json.dumps(out, indent=1)[:1500])
+json.dump(parse(f"gpurun_out/pmc_{tag}_sq.txt"), open(f"profiles/{rnd}_pmc_sq_{cfg}.json", "w"), indent=1)
+print("kernels:", sorted(doc[cfg]["kernels"]))
