@@ -57,7 +57,7 @@ def test_struct_layouts_match_header():
             decl = decl.strip()
             if not decl:
                 continue
-            decl = re.sub(r"^(const\s+)?(float|int32_t|int64_t|uint64_t|void)\s*", "", decl)
+            decl = re.sub(r"^(const\s+)?(float|int32_t|int64_t|uint64_t|uint8_t|void)\s*", "", decl)
             out += [x.strip().lstrip("*").strip() for x in decl.split(",")]
         return out
 
