@@ -146,6 +146,8 @@ class SceneModel(nn.Module):
         self.move_model = MoveModel(num_fg=self.num_fg_gaussians, camera_mode="linear").to(Ks.device)
         self.inplace_blend_quirk = True  # exposure_imgs[-1] is the blended frame (scene_model.py:391,486)
         self._stats_sink = None
+        self.deferred_size_check = False  # True: renders never wait for the device-side intersection count (engine
+        #                                   RenderCfg.deferred_size_check; call engine.check_deferred() once per step)
 
     def attach_control_stats(self, running_stats: dict, batch_size: int, update_max_radii: bool = False):
         """SURVEY 8f-1, fused: until `detach_control_stats()`, the backward of every full render (all Gaussians, no
@@ -309,7 +311,8 @@ class SceneModel(nn.Module):
             self.motion_bases.params["rots"] if G > 0 else None, self.motion_bases.params["transls"] if G > 0 else None,
             times_s if G > 0 else None, RTs_s, w2cs[0], Ks[0], W, H, background=bg_color[0], return_depth=return_depth,
             policy=None, blend=True,
-            control_stats=self._sink_for(N) if (which == "all" and filter_mask is None) else None)
+            control_stats=self._sink_for(N) if (which == "all" and filter_mask is None) else None,
+            deferred_size_check=self.deferred_size_check)
         blended = res["blended"][None]  # [1,H,W,D']
         renders = res["renders"]
 

@@ -20,6 +20,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+from deblur4dgs_amd import engine  # noqa: E402
 from deblur4dgs_amd.control import ControlCfg, accumulate_from_model, cull_step, densify_step  # noqa: E402
 from deblur4dgs_amd.losses import photometric_loss  # noqa: E402
 from deblur4dgs_amd.scene_model import GaussianParams, MotionBases, SceneModel  # noqa: E402
@@ -36,8 +37,12 @@ def build(n_fg=40_000, n_bg=100_000, K=20, W=512, H=288, dev="cuda:0", seed=0):
     return model.to(dev), sc
 
 
-def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, **kw):
+def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, fused_stats=True, deferred=True, **kw):
+    """fused_stats: the densification statistics come out of the rasterizer's backward (attach_control_stats) instead
+    of a pass over `_current_xys[i].grad`; deferred: no render waits for its intersection count on the host
+    (`deferred_size_check`), the counts are verified once per step."""
     model, sc = build(W=W, H=H, dev=dev, **kw)
+    model.deferred_size_check = bool(deferred)
     w2c, K = sc["viewmat"][None].to(dev), sc["K"][None].to(dev)
     # targets: renders of a perturbed copy of the scene (so the loss has something to fit)
     with torch.no_grad():
@@ -66,8 +71,11 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, *
         for o in opts():
             o.zero_grad(set_to_none=True)
         out1 = model.render(3, w2c, K, (W, H), bg_only=True, return_depth=True, return_mask=True, mode="blury")
+        if fused_stats:  # statistics of the dynamic render, accumulated by its own backward (trainer.py:953-990)
+            model.attach_control_stats(stats, batch_size=1)
         out2 = model.render(3, w2c, K, (W, H), target_ts=target_ts, target_w2cs=target_w2cs, return_depth=True,
                             return_mask=True, mode="blury")  # 17 channels
+        model.detach_control_stats()
         xys2, radii2, wh2 = model._current_xys, model._current_radii, model._current_img_wh
         out3 = model.render(3, w2c, K, (W, H), bg_only=True, return_depth=True, mode="mid")
         # the reference's photometric term, 0.8 L1 + 0.2 (1 - SSIM) (trainer.py:388-392,575-586), fused
@@ -76,8 +84,11 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, *
         loss.backward()
         for o in opts():
             o.step()
-        model._current_xys, model._current_radii, model._current_img_wh = xys2, radii2, wh2
-        accumulate_from_model(stats, model, batch_size=1)
+        if not fused_stats:
+            model._current_xys, model._current_radii, model._current_img_wh = xys2, radii2, wh2
+            accumulate_from_model(stats, model, batch_size=1)
+        if deferred:
+            engine.check_deferred()  # raises if a render of this step overflowed its intersection lists
         losses.append(loss.detach())  # no host sync inside the loop
         if control_every and it > 0 and it % control_every == 0:  # adaptive control: N changes between steps
             n_split, n_dup = densify_step(model, stats, optimizers, cfg, global_step=it)
@@ -101,5 +112,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--control-every", type=int, default=0, help="densify + cull every N steps (0: never)")
+    ap.add_argument("--round1", action="store_true", help="statistics as a separate pass, host waits for every list size")
     a = ap.parse_args()
-    train(a.steps, control_every=a.control_every)
+    train(a.steps, control_every=a.control_every, fused_stats=not a.round1, deferred=not a.round1)

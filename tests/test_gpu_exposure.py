@@ -154,3 +154,22 @@ def test_grad_arena_receives_the_leaf_gradients_without_copies():
     for k in names:
         assert got[k].grad.data_ptr() == arena[k].data_ptr(), k
         assert torch.equal(got[k].grad, ref[k].grad), k
+
+
+def test_leaves_are_version_checked_between_forward_and_backward():
+    """the projection backward re-reads the leaf parameters; they travel through save_for_backward, so an
+    in-place update after the forward (optimizer.step, reset_opacities' fill_, a control step) raises in backward, as
+    stock autograd / gsplat would, instead of silently differentiating the modified values."""
+    from deblur4dgs_amd.exposure import render_exposure
+
+    dev = torch.device("cuda:0")
+    sc = make_scene(2000, 1200, 4, 2, 96, 64, seed=3)
+    names = ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls", "times", "RTs", "viewmat")
+    for victim in ("opacities", "rots", "means"):
+        L = {k: sc[k].to(dev).clone().requires_grad_() for k in names}
+        res = render_exposure(L["means"], L["quats"], L["scales"], L["opacities"], L["colors"], 3, L["motion_coefs"], L["rots"],
+                              L["transls"], L["times"], L["RTs"], L["viewmat"], sc["K"].to(dev), 96, 64, return_depth=True)
+        with torch.no_grad():
+            L[victim].data.fill_(0.5) if victim == "opacities" else L[victim].add_(0.1)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            res["blended"].sum().backward()
