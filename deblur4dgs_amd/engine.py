@@ -239,8 +239,8 @@ class ProjectFn(torch.autograd.Function):
         ctx.st = st
         # The backward re-reads the leaves.  `_f32c` hands out detached ALIASES of f32-contiguous leaves, which share the
         # leaf's version counter: routing them through save_for_backward makes an in-place update between forward and
-        # backward (optimizer.step, reset_opacities' fill_, a control step) raise, as stock autograd / gsplat would,
-        # instead of silently differentiating modified parameters.
+        # backward (optimizer.step, a control step) raise, as stock autograd / gsplat would, instead of silently
+        # differentiating modified parameters.  (Writes through `.data` bypass version counters everywhere.)
         ctx.save_for_backward(*[st.proj_in[k] for k in _PROJ_IN])
         ctx.needs = [t is not None and t.requires_grad for t in
                      (means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat)]
