@@ -149,6 +149,66 @@ def test_any_channel_layout_matches_the_reference_policy(has_bg, B, depth, mask)
         check(case, name, got_p.grad.cpu(), ref_p.grad, 1e-4, GRAD_FLIP_FRAC)
 
 
+@pytest.mark.parametrize("which,mode,use_filter", [("fg", "start", False), ("bg", "end", False), ("all", "mid", True),
+                                                   ("fg", "blury", True)])
+def test_render_variants_match_oracle(which, mode, use_filter):
+    """The other call shapes of `render()` the reference uses (scene_model.py:196-232,298-321,355-358): fg_only / bg_only
+    (validator.py:104-151, trainer.py:320), mode start / end / mid, and `filter_mask` - images and gradients against the
+    oracle evaluated on the same subset of Gaussians."""
+    dev = torch.device("cuda:0")
+    N, G, K, W, H = 800, 450, 3, 64, 48
+    model, sc = _build(N, G, K, W, H, 41, dev)
+    fm = None
+    if use_filter:
+        n_sel = {"fg": G, "bg": N - G, "all": N}[which]
+        fm = torch.rand(n_sel, generator=torch.Generator().manual_seed(5)) < 0.7
+    t, stage = 3.0, "second"
+    dd = lambda x: x.detach().double().cpu().clone()
+    pick = lambda params, m: {k: (dd(v) if m is None else dd(v)[m]).requires_grad_() for k, v in params.items()}
+    fg = bg = None
+    if which in ("fg", "all"):
+        fg = pick(model.fg.params, None if fm is None else fm[:G])
+    if which in ("bg", "all"):
+        bg = pick(model.bg.params, None if fm is None else (fm if which == "bg" else fm[G:]))
+    bases = {k: dd(v).requires_grad_() for k, v in model.motion_bases.params.items()} if fg is not None else None
+    sd = {k: v.detach().cpu().double() for k, v in model.move_model.state_dict().items()}
+    w2c = sc["viewmat"].double()
+    RTs, times, dT = ocam.forward_start_end_mid(sd, w2c[:3, :3], w2c[:3, 3:4], t, 11, stage)
+    sel = {"mid": slice(5, 6), "start": slice(0, 1), "end": slice(10, 11)}.get(mode, slice(None))
+    ref = oscene.render_exposure(fg, bg, bases, times[0, sel], RTs[sel], w2c, sc["K"].double(), (W, H), bg_color=1.0,
+                                 return_depth=True, return_mask=True, single=mode in ("mid", "start", "end"))
+    out = model.render(t, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H), return_depth=True, return_mask=True,
+                       fg_only=which == "fg", bg_only=which == "bg", filter_mask=None if fm is None else fm.to(dev),
+                       mode=mode, stage=stage)
+    case = f"S2 variant {which} mode={mode} filter={use_filter}"
+    for k in ("img", "mask", "depth", "acc"):
+        check(case, k, out[k].cpu(), ref[k], 1e-4, GRAD_FLIP_FRAC)
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(1, H, W, 3, generator=g)
+    ((out["img"] * w.to(dev)).sum() + out["depth"].sum()).backward()
+    ((ref["img"] * w.double()).sum() + ref["depth"].sum()).backward()
+    torch.cuda.synchronize()
+    if fg is not None:
+        m = None if fm is None else fm[:G]
+        for k in ("means", "opacities", "motion_coefs"):
+            got = model.fg.params[k].grad.cpu()
+            want = torch.zeros_like(got, dtype=torch.float64)
+            if m is None:
+                want = fg[k].grad
+            else:
+                want[m] = fg[k].grad  # filtered-out Gaussians receive no gradient
+            check(case, f"fg.{k}", got, want, 1e-4, GRAD_FLIP_FRAC)
+    if bg is not None:
+        m = None if fm is None else (fm if which == "bg" else fm[G:])
+        got = model.bg.params["scales"].grad.cpu()
+        want = torch.zeros_like(got, dtype=torch.float64)
+        if m is None:
+            want = bg["scales"].grad
+        else:
+            want[m] = bg["scales"].grad
+        check(case, "bg.scales", got, want, 1e-4, GRAD_FLIP_FRAC)
+
+
 def test_render_from_a_loaded_reference_checkpoint(tmp_path):
     """save the reference Trainer's checkpoint dict, load it back, render on the device: the images equal
     the original model's once its exposure half-widths are at 0.5 too (the loader resets `time_params`)."""
