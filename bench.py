@@ -331,10 +331,10 @@ def main():
         for _ in range(warmup):
             step()
         sync()
-        if args.graph and sharder is None:  # same kernels, same arithmetic; one hipGraphLaunch per step
+        if args.graph and sharder is None:  # same kernels, same arithmetic; one hipGraphLaunch per step.  (Capturing the
+            # sharded step with its RCCL collectives faulted the GPU in a world-size-1 trial - not offered.)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            kw_def = dict(deferred_size_check=True)
 
             def gstep():
                 for v in leaves.values():
@@ -342,7 +342,7 @@ def main():
                 res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                       leaves["colors"], 3, leaves.get("motion_coefs"), leaves.get("rots"),
                                       leaves.get("transls"), leaves.get("times"), leaves["RTs"], leaves["viewmat"], d["K"],
-                                      W, H, background=bg, return_depth=True, **kw_def)
+                                      W, H, background=bg, return_depth=True, deferred_size_check=True)
                 loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
                 loss.backward()
                 return res["state"]
@@ -355,7 +355,7 @@ def main():
                 v.grad = None
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                gstate = gstep()
+                gstep()
             real_state = last["st"]
 
             def step():  # noqa: F811
@@ -510,9 +510,14 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Gaussians/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out))
+    sys.stdout.flush()
     if use_dist:
         import torch.distributed as dist
 
+        # RCCL prints a version banner (RCCL / HIP / ROCm version, hostname, library path) to the C-level stdout of every
+        # rank, flushed at exit: the contract is ONE JSON line on stdout, so whatever the library still holds goes to
+        # /dev/null from here on
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
         dist.destroy_process_group()
 
 

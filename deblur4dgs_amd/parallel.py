@@ -5,8 +5,8 @@ constrained only by "the sharded result equals the single-GPU result":
 
 * exposure sharding (BASELINE config 4): the S sub-samples of ONE blurry frame are independent given replicated
   leaf parameters (flow3d/scene_model.py:323-384); rank r renders {s : s % P == r}.  The only coupling is the blend
-  (scene_model.py:386-397).  Default (`GatherBlendFn`, needs S % P == 0): ONE all-gather of the ranks' sub-sample
-  images [S/P,H,W,D'+1] puts the whole S-stack on every rank, which then runs the same HIP blend kernels as the
+  (scene_model.py:386-397).  Default (`GatherBlendFn`, needs S % P == 0): an all-gather of the ranks' sub-sample
+  colour images [S/P,H,W,D'] and one of their alphas put the whole S-stack on every rank, which then runs the same HIP blend kernels as the
   single-GPU path (`k_blend_fwd/bwd`) - the blended image is BITWISE the single-GPU image (same summation order),
   the max / min channels and their winners need no extra collective, the backward keeps the slice of the stack
   gradient that belongs to the rank's own sub-samples (the loss is evaluated redundantly, so no reduction), and the
@@ -103,21 +103,26 @@ class GatherBlendFn(torch.autograd.Function):
         Sl, H, W, Cn = renders.shape
         P = S // Sl
         assert Sl * P == S and P == dist.get_world_size(group), "GatherBlendFn needs S % world_size == 0"
-        packed = torch.cat([renders, alphas[..., None]], -1).contiguous()  # [Sl,H,W,C+1]
-        full = torch.empty(P * Sl, H, W, Cn + 1, dtype=renders.dtype, device=renders.device)
-        dist.all_gather_into_tensor(full, packed, group=group)  # rank-major concatenation along dim 0
-        # rank r holds s = j * P + r (owned_subsamples): [P,Sl] -> s-major
-        stack = full.view(P, Sl, H, W, Cn + 1).transpose(0, 1).reshape(S, H, W, Cn + 1)
+        # two all-gathers straight into the blend kernel's input layout (colours [S,H,W,C], alphas [S,H,W]): no packing
+        # copy; with one sub-sample per rank (BASELINE cfg4) the rank-major result IS the s-major stack
+        full_r = torch.empty(P * Sl, H, W, Cn, dtype=renders.dtype, device=renders.device)
+        full_a = torch.empty(P * Sl, H, W, dtype=alphas.dtype, device=alphas.device)
+        dist.all_gather_into_tensor(full_r, renders.contiguous(), group=group)
+        dist.all_gather_into_tensor(full_a, alphas.contiguous(), group=group)
+        if Sl > 1:  # rank r holds s = j * P + r (owned_subsamples): [P,Sl] -> s-major
+            full_r = full_r.view(P, Sl, H, W, Cn).transpose(0, 1).reshape(S, H, W, Cn)
+            full_a = full_a.view(P, Sl, H, W).transpose(0, 1).reshape(S, H, W)
         with torch.enable_grad():
-            st_r = stack[..., :Cn].contiguous().requires_grad_()
-            st_a = stack[..., Cn].contiguous().requires_grad_()
+            st_r = full_r.requires_grad_()
+            st_a = full_a.requires_grad_()
             out, acc = blend_fn(st_r, st_a, policy)
+        stack = (st_r.detach(), st_a.detach())
         ctx.save_for_backward(st_r, st_a, out, acc)
         ctx.meta = (S, Sl, P, dist.get_rank(group))
-        return out.detach(), acc.detach(), stack.detach()
+        return out.detach(), acc.detach(), stack[0], stack[1]
 
     @staticmethod
-    def backward(ctx, v_out, v_acc, v_stack):
+    def backward(ctx, v_out, v_acc, v_stack_r, v_stack_a):
         st_r, st_a, out, acc = ctx.saved_tensors
         S, Sl, P, rank = ctx.meta
         outs, grads = [], []
@@ -128,9 +133,10 @@ class GatherBlendFn(torch.autograd.Function):
         g_r, g_a = torch.autograd.grad(outs, [st_r, st_a], grads, allow_unused=True) if outs else (None, None)
         g_r = torch.zeros_like(st_r) if g_r is None else g_r
         g_a = torch.zeros_like(st_a) if g_a is None else g_a
-        if v_stack is not None:  # losses on the per-sub-sample images (trainer.py:599-618)
-            g_r = g_r + v_stack[..., :-1]
-            g_a = g_a + v_stack[..., -1]
+        if v_stack_r is not None:  # losses on the per-sub-sample images (trainer.py:599-618)
+            g_r = g_r + v_stack_r
+        if v_stack_a is not None:
+            g_a = g_a + v_stack_a
         own = slice(rank, S, P)  # this rank's sub-samples; the loss is replicated, so their gradient is local
         return g_r[own].contiguous(), g_a[own].contiguous(), None, None, None, None
 
@@ -219,6 +225,8 @@ class ShardedExposure:
         assert mode in ("exposure", "views")
         self.world, self.rank, self.mode, self.group = world, rank, mode, group
         self.reducer = None
+        self.deferred_size_check = False  # True: no render waits for its list sizes on the host (engine.RenderCfg) - needed
+        #                                   to capture the step, collectives included, in a HIP graph
 
     def step(self, leaves: dict, Kmat, W: int, H: int, background, wimg, wacc):
         from .exposure import render_exposure
@@ -235,7 +243,8 @@ class ShardedExposure:
             res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                   leaves["colors"], 3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                                   leaves["times"], leaves["RTs"], leaves["viewmat"], Kmat, W, H, background=background,
-                                  return_depth=True, grad_arena=self.reducer.views)
+                                  return_depth=True, grad_arena=self.reducer.views,
+                                  deferred_size_check=self.deferred_size_check)
             loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
             # data-parallel mean of the per-view gradients: the 1 / world factor rides on the loss, so the SUM
             # all-reduce needs no 24 MB division pass afterwards
@@ -244,18 +253,18 @@ class ShardedExposure:
             self.reducer.reduce(leaves)
             return res["state"]
         own = owned_subsamples(S, self.world, self.rank)
-        idx = torch.tensor(own, device=leaves["times"].device, dtype=torch.long)
+        sel = slice(self.rank, S, self.world)  # == own, as a strided view (no index tensor, no host-side index build)
         res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
                               3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
-                              leaves["times"].index_select(0, idx), leaves["RTs"].index_select(0, idx),
+                              leaves["times"][sel], leaves["RTs"][sel],
                               leaves["viewmat"], Kmat, W, H, background=background, return_depth=True, blend=False,
-                              grad_arena=self.reducer.views)
+                              grad_arena=self.reducer.views, deferred_size_check=self.deferred_size_check)
         pol = reference_policy(res["renders"].shape[-1])
         if S % self.world == 0:  # one all-gather, then the single-GPU blend kernels on the full stack (bitwise equal)
             from .exposure import BlendFn
 
-            blended, acc, _stack = GatherBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), S, pol, self.group,
-                                                       BlendFn.apply)
+            blended, acc, _stack_r, _stack_a = GatherBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), S, pol,
+                                                                   self.group, BlendFn.apply)
         else:
             blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), own, S, pol, self.group)
         loss = torch.dot(blended.reshape(-1), wimg.reshape(-1)) + torch.dot(acc.reshape(-1), wacc.reshape(-1))

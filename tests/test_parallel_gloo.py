@@ -117,7 +117,8 @@ def _gather_worker(rank, world, port, S, C, seed, q):
     loc = renders[own] * scale[own].view(-1, 1, 1, 1) * means.sum() / 3.0
     loc.retain_grad()
     la = alphas[own].clone().requires_grad_()
-    out, acc, stack = GatherBlendFn.apply(loc, la, S, reference_policy(C), None, _oracle_blend)
+    out, acc, stack_r, stack_a = GatherBlendFn.apply(loc, la, S, reference_policy(C), None, _oracle_blend)
+    stack = torch.cat([stack_r, stack_a[..., None]], -1)
     leaves = {"scale": scale, "means": means}
     red = FlatGradAllReduce(leaves)
     red.arm(leaves)
