@@ -33,7 +33,17 @@ struct RasterBwdArgs {
   const float *v_out;
   const float *v_alphas;  // may be null
   float *isect_grad;
+  const int64_t *n_dev;  // device {total, longest list}; the lists were sized for (cap, max_hint) - see binning.hip
+  int64_t cap, max_hint;
 };
+
+// The forward stage skips its work when the device-side intersection count exceeds what the caller sized the lists for
+// (optimistic / deferred sizing, engine.py).  The backward must not touch those lists either: tile_offsets are computed from
+// the TRUE counts and would index past the end of sorted_gid / isect_grad.
+__device__ __forceinline__ bool lists_overflowed(const int64_t *n_dev, int64_t cap, int64_t max_hint) {
+  return n_dev && (n_dev[0] > cap || (max_hint > 0 && n_dev[1] > max_hint));
+}
+
 
 __device__ __forceinline__ int xcd_remap_b(int b, int n_blocks) {
   const int per = (n_blocks + 7) >> 3;
@@ -58,6 +68,7 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
   __shared__ float4 scol[64 * DV];
   __shared__ float sgrad[64 * RP];
 
+  if (lists_overflowed(a.n_dev, a.cap, a.max_hint)) return;
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
   const int t = xcd_remap_b(blockIdx.x, n_tiles);
@@ -247,6 +258,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   __shared__ float sgrad[4 * NB * RP];
   __shared__ int shi[4];
 
+  if (lists_overflowed(a.n_dev, a.cap, a.max_hint)) return;
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
   const int t = xcd_remap_b(blockIdx.x, n_tiles);
@@ -520,6 +532,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
   __shared__ int shit[4 * HF];
   __shared__ int shi[4];
 
+  if (lists_overflowed(a.n_dev, a.cap, a.max_hint)) return;
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
   const int t = xcd_remap_b(blockIdx.x, n_tiles);
@@ -749,6 +762,8 @@ struct GatherArgs {
   const int32_t *tiles_touched;
   const int32_t *isect_offsets;
   const float *isect_grad;
+  const int64_t *n_dev;  // see RasterBwdArgs: an overflowed render has no valid rows - its gradients are zeros
+  int64_t cap, max_hint;
   float *v_means2d, *v_conics, *v_depths, *v_opac_act, *v_ctab;
   // fused densification statistics (trainer.py:967-989); stats_acc == nullptr: off
   const int32_t *radii;
@@ -777,13 +792,14 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
 #pragma unroll
   for (int c = 0; c < D; c++) vc[c] = 0.f;
   // densification statistics of this Gaussian, accumulated over the sub-samples in order (k_control_stats' arithmetic)
-  const bool stats = a.stats_acc != nullptr;
+  const bool overflow = lists_overflowed(a.n_dev, a.cap, a.max_hint);  // grid-uniform
+  const bool stats = a.stats_acc != nullptr && !overflow;
   float st_acc = 0.f, st_mr = 0.f;
   int64_t st_vis = 0;
   if (stats && in) st_acc = a.stats_acc[g], st_vis = a.stats_vis[g], st_mr = a.stats_mr[g];
   for (int s = 0; s < a.S; s++) {
     const size_t i = (size_t)s * a.N + (in ? g : a.N - 1);
-    const int cnt = in ? a.tiles_touched[i] : 0;
+    const int cnt = (in && !overflow) ? a.tiles_touched[i] : 0;
     const int off = a.isect_offsets[i];
     // span of the wave: [first lane's offset, last lane's offset + count)
     const int base = __builtin_amdgcn_readfirstlane(off);
@@ -883,7 +899,9 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.sorted_emit = isect->sorted_emit;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad;
+  a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
   GatherArgs ga;
+  ga.n_dev = proj->n_isect, ga.cap = isect->n_isect, ga.max_hint = isect->max_tile_count;
   ga.N = dims->N, ga.S = dims->S, ga.D = dims->D, ga.DP = (dims->D + 3) & ~3;
   ga.depth = dims->depth_mode != D4GS_DEPTH_NONE;
   ga.tiles_touched = proj->tiles_touched, ga.isect_offsets = proj->isect_offsets, ga.isect_grad = g->isect_grad;

@@ -37,10 +37,14 @@ def build(n_fg=40_000, n_bg=100_000, K=20, W=512, H=288, dev="cuda:0", seed=0):
     return model.to(dev), sc
 
 
-def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, fused_stats=True, deferred=True, **kw):
+def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, fused_stats=True, deferred=True,
+          graph=False, **kw):
     """fused_stats: the densification statistics come out of the rasterizer's backward (attach_control_stats) instead
     of a pass over `_current_xys[i].grad`; deferred: no render waits for its intersection count on the host
-    (`deferred_size_check`), the counts are verified once per step."""
+    (`deferred_size_check`), the counts are verified once per step; graph: the three renders, the loss and the whole
+    backward of a step are captured ONCE in a HIP graph (after two eager warm-up steps) and replayed - the step is then
+    one hipGraphLaunch plus the optimizers (re-captured whenever a control step changes N)."""
+    assert not graph or (fused_stats and deferred), "graph capture needs the sync-free step"
     model, sc = build(W=W, H=H, dev=dev, **kw)
     model.deferred_size_check = bool(deferred)
     w2c, K = sc["viewmat"][None].to(dev), sc["K"][None].to(dev)
@@ -49,7 +53,9 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, f
         tgt_model, _ = build(W=W, H=H, dev=dev, seed=1, **kw)
         tgt_dyn = tgt_model.render(3, w2c, K, (W, H), mode="blury")["img"]
         tgt_sta = tgt_model.render(3, w2c, K, (W, H), bg_only=True, mode="blury")["img"]
-    adam = lambda p, lr: torch.optim.Adam([p], lr=lr, fused=p.is_cuda)
+    # (torch's fused Adam faults the GPU when its gradients live in a CUDA-graph memory pool - scripts/graph_bisect.py;
+    # the graph mode therefore uses the plain implementation)
+    adam = lambda p, lr: torch.optim.Adam([p], lr=lr, fused=p.is_cuda and not graph)
     lrs = {"means": 1.6e-4, "colors": 1e-2, "opacities": 1e-2, "scales": 5e-3, "quats": 5e-3, "motion_coefs": 5e-3}
     # one Adam per tensor, keyed like the reference's Trainer.optimizers (trainer.py:1168-1196): the control steps
     # re-key them when rows are added / removed
@@ -64,24 +70,48 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, f
     target_w2cs = w2c.expand(4, 4, 4).contiguous()
     losses = []
     warm = min(5, steps // 2)  # lazy initialisation (Adam state, code objects) stays out of the timing
-    for it in range(steps):
-        if it == warm:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        for o in opts():
-            o.zero_grad(set_to_none=True)
+    def fwd_bwd():
         out1 = model.render(3, w2c, K, (W, H), bg_only=True, return_depth=True, return_mask=True, mode="blury")
         if fused_stats:  # statistics of the dynamic render, accumulated by its own backward (trainer.py:953-990)
             model.attach_control_stats(stats, batch_size=1)
         out2 = model.render(3, w2c, K, (W, H), target_ts=target_ts, target_w2cs=target_w2cs, return_depth=True,
                             return_mask=True, mode="blury")  # 17 channels
         model.detach_control_stats()
-        xys2, radii2, wh2 = model._current_xys, model._current_radii, model._current_img_wh
+        side = (model._current_xys, model._current_radii, model._current_img_wh)
         out3 = model.render(3, w2c, K, (W, H), bg_only=True, return_depth=True, mode="mid")
         # the reference's photometric term, 0.8 L1 + 0.2 (1 - SSIM) (trainer.py:388-392,575-586), fused
         loss = photometric_loss(out1["img"], tgt_sta) + photometric_loss(out2["img"], tgt_dyn) + \
             0.1 * photometric_loss(out3["img"], tgt_sta) + 1e-3 * out2["tracks_3d"].square().mean()
         loss.backward()
+        return loss.detach(), side
+
+    params = [p for o in opts() for g in o.param_groups for p in g["params"]]
+    captured = None  # (graph, static loss)
+    eager_since_capture = 0
+    for it in range(steps):
+        if it == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        if graph and captured is not None and it % 25 == 0:
+            # a replayed graph keeps the list capacities of its capture and nobody looks at the device-side counts: go
+            # back to two eager (deferred-checked) steps now and then, so the capacities follow the scene as it trains
+            captured, eager_since_capture = None, 0
+        if graph and captured is None and eager_since_capture >= 2:
+            for p_ in params:
+                p_.grad = None
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                loss_static, _ = fwd_bwd()
+            captured = (g_, loss_static)
+        if captured is not None:
+            captured[0].replay()  # gradients land in the same .grad tensors every step
+            loss, side = captured[1], None
+        else:
+            for o in opts():
+                o.zero_grad(set_to_none=True)
+            loss, side = fwd_bwd()
+            eager_since_capture += 1
+        xys2, radii2, wh2 = side if side is not None else (None, None, None)
         for o in opts():
             o.step()
         if not fused_stats:
@@ -89,12 +119,14 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, f
             accumulate_from_model(stats, model, batch_size=1)
         if deferred:
             engine.check_deferred()  # raises if a render of this step overflowed its intersection lists
-        losses.append(loss.detach())  # no host sync inside the loop
+        losses.append(loss.detach().clone())  # no host sync inside the loop
         if control_every and it > 0 and it % control_every == 0:  # adaptive control: N changes between steps
             n_split, n_dup = densify_step(model, stats, optimizers, cfg, global_step=it)
             n_cull = cull_step(model, stats, optimizers, cfg, global_step=it)
             for v in stats.values():
                 v.zero_()
+            params = [p for o in opts() for g in o.param_groups for p in g["params"]]
+            captured, eager_since_capture = None, 0  # N changed: new shapes, new parameters -> capture again
             if verbose:
                 print(f"step {it:3d}  control: split {n_split}, dup {n_dup}, cull {n_cull} -> {model.num_gaussians} Gaussians")
         if verbose and (it % 10 == 0 or it == steps - 1):
@@ -113,5 +145,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--control-every", type=int, default=0, help="densify + cull every N steps (0: never)")
     ap.add_argument("--round1", action="store_true", help="statistics as a separate pass, host waits for every list size")
+    ap.add_argument("--graph", action="store_true", help="replay the step's renders + loss + backward from a HIP graph")
     a = ap.parse_args()
-    train(a.steps, control_every=a.control_every, fused_stats=not a.round1, deferred=not a.round1)
+    train(a.steps, control_every=a.control_every, fused_stats=not a.round1, deferred=not a.round1, graph=a.graph)
