@@ -1,0 +1,52 @@
+"""Host-side logic of the engine that needs no GPU: channel chunking, sort size classes, the bounded size-guess cache."""
+import torch
+
+from deblur4dgs_amd import engine
+
+
+def test_channel_chunks_cover_every_count_with_instantiated_widths():
+    for D in range(0, 70):
+        ch = engine.channel_chunks(D)
+        assert ch[0][0] == 0 and ch[-1][1] == D
+        for (a, b, w), nxt in zip(ch, ch[1:] + [None]):
+            assert w in engine.SUPPORTED_D and b - a <= w and (b - a == 16 or nxt is None)
+            if nxt is not None:
+                assert nxt[0] == b
+        if D in engine.SUPPORTED_D:
+            assert ch == [(0, D, D)]  # the common case: one pass, nothing padded
+    # the reference's layouts: 3 + mask + 3B track channels (+ depth rides on the last chunk)
+    assert engine.channel_chunks(16) == [(0, 16, 16)]
+    assert engine.channel_chunks(3 + 1 + 18) == [(0, 16, 16), (16, 22, 8)]
+
+
+def test_sort_classes_leave_headroom_and_fall_back_to_unknown():
+    assert engine._sort_class(0) == 2048 and engine._sort_class(1365) == 2048
+    assert engine._sort_class(1366) == 4096 and engine._sort_class(5000) == 8192 and engine._sort_class(10922) == 16384
+    assert engine._sort_class(10923) == 0  # longer than the largest LDS class with 50 % headroom: every class is launched
+
+
+def test_size_guess_cache_is_bounded_and_buckets_n():
+    dev = torch.device("cuda", 0)  # only .index is used
+    k1, k2 = engine._size_key(dev, 8, 300_000, 512, 288), engine._size_key(dev, 8, 310_000, 512, 288)
+    assert k1 == k2  # densification moves N a little: same entry (two leading bits)
+    assert engine._size_key(dev, 8, 600_000, 512, 288) != k1
+    engine._SIZE_GUESS.clear()
+    for i in range(3 * engine._SIZE_GUESS_MAX):
+        engine._guess_put(("k", i), (i, 2048))
+    assert len(engine._SIZE_GUESS) == engine._SIZE_GUESS_MAX
+    assert engine._guess_get(("k", 0)) is None and engine._guess_get(("k", 3 * engine._SIZE_GUESS_MAX - 1)) is not None
+    engine._SIZE_GUESS.clear()
+
+
+def test_control_stats_sink_is_validated():
+    import pytest
+
+    good = {"xys_grad_norm_acc": torch.zeros(5), "vis_count": torch.zeros(5, dtype=torch.int64), "max_radii": torch.zeros(5),
+            "batch_size": 2}
+    assert engine._check_stats(good, 5) is good
+    with pytest.raises(ValueError):
+        engine._check_stats(good, 6)
+    with pytest.raises(ValueError):
+        engine._check_stats({**good, "vis_count": torch.zeros(5)}, 5)
+    with pytest.raises(ValueError):
+        engine._check_stats({**good, "batch_size": 0}, 5)
