@@ -59,8 +59,7 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
   float *Bs = smem;                  // [S][K][9]
   float *cf = Bs + nBs;              // [BLK][KP]   softmaxed coefficients
   float *vcf = cf + BLK * KP;        // [BLK][KP]   their gradients, summed over s
-  float *sv = vcf + BLK * KP;        // [BLK][NV]   per-s vectors to be column-reduced
-  float *psum = sv + BLK * NV;       // [4][9K+13]  per-wave segment sums (+ dump slot)
+  float *psum = vcf + BLK * KP;       // [2][4][9K+13]  per-wave segment sums (+ dump slot), double-buffered over s
   const int tid = threadIdx.x;
   const int g = blockIdx.x * BLK + tid;
   const Cam cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
@@ -312,8 +311,10 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
     if (dyn || a.in.RTs) {
       const int nk = dyn ? K * 9 : 0, no = nk + 12, nop = no + 1;  // +1: wave_sum_store's dump slot
       const int lane = tid & 63, seg = tid >> 6;
-      float *mine = psum + seg * nop;
-      __syncthreads();  // the previous sub-sample's psum has been consumed
+      // double-buffered over s: the buffer written now was last read two sub-samples ago, before the barrier of s - 1,
+      // so ONE barrier per sub-sample (writes -> reads) is enough
+      float *pb = psum + (s & 1) * 4 * nop;
+      float *mine = pb + seg * nop;
       if (dyn) {
         if (dyn_block) {
           for (int k = 0; k < K; k++) {
@@ -335,22 +336,17 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
       }
       __syncthreads();
       for (int o = tid; o < no; o += BLK)
-        part[s * no + o] = (psum[o] + psum[nop + o]) + (psum[2 * nop + o] + psum[3 * nop + o]);
+        part[s * no + o] = (pb[o] + pb[nop + o]) + (pb[2 * nop + o] + pb[3 * nop + o]);
     }
   }
 
-  // ---- viewmat partials (12 plain column sums) ----
+  // ---- viewmat partials (12 plain column sums): the same per-wave ladder + fixed-order sum of the 4 segments ----
   {
     const int nk = dyn ? K * 9 : 0;
+    __syncthreads();  // the last sub-sample's psum has been consumed
+    wave_sum_store(v_view, psum + (tid >> 6) * 13, tid & 63);
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 12; r++) sv[tid * NV + r] = v_view[r];
-    __syncthreads();
-    if (tid < 12) {
-      float acc = 0.f;
-      for (int t = 0; t < BLK; t++) acc += sv[t * NV + tid];
-      part[S * (nk + 12) + tid] = acc;
-    }
+    if (tid < 12) part[S * (nk + 12) + tid] = (psum[tid] + psum[13 + tid]) + (psum[26 + tid] + psum[39 + tid]);
   }
 
   if (!active) return;
@@ -406,35 +402,36 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float *partials, 
   if (o < n && lane == 0) out[o] = acc;
 }
 
-// scatter the reduced shared gradients: v_Bs -> rots / transls / times ; camera deltas ; viewmat.  One block.
+// scatter the reduced shared gradients: v_Bs -> rots / transls / times ; camera deltas ; viewmat.
+// One thread per LEAF element (basis k, frame, component): it walks the sub-samples in order and adds the (1 - w) share
+// of those whose floor frame it is, then the w share of those whose ceil frame it is - independent loads, one store, no
+// read-modify-write chains through memory (the first version's (k, j) owners did S dependent global updates: 9 us).
 __global__ void __launch_bounds__(256) k_finish(const BwdArgs a, const float *red) {
   const D4gsDims &d = a.d;
   const int K = d.K, T = d.T, S = d.S;
   const bool dyn = d.G > 0;
   const int nk = dyn ? K * 9 : 0;
   const int stride = nk + 12;
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
   if (dyn) {
-    for (int idx = threadIdx.x; idx < K * T * 6; idx += blockDim.x) a.g.v_rots[idx] = 0.f;
-    for (int idx = threadIdx.x; idx < K * T * 3; idx += blockDim.x) a.g.v_transls[idx] = 0.f;
-    __syncthreads();
-    // each (k, j) owner walks the sub-samples in order: no two threads touch the same leaf element
-    for (int o = threadIdx.x; o < K * 9; o += blockDim.x) {
-      const int k = o / 9, j = o - k * 9;
+    if (gtid < K * T * 9) {
+      const int k = gtid / (T * 9), r = gtid - k * T * 9, fr = r / 9, j = r - fr * 9;
+      float acc = 0.f;
       for (int s = 0; s < S; s++) {
         const float t = a.in.times[s];
         const float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));
         const float cfl = fminf(fmaxf(ceilf(t), 0.f), (float)(T - 1));
         const float w = t - ff;
-        const int f = (int)ff, c = (int)cfl;
-        const float v = red[s * stride + o];
-        float *base = j < 3 ? a.g.v_transls : a.g.v_rots;
-        const int width = j < 3 ? 3 : 6, jj = j < 3 ? j : j - 3;
-        base[(k * T + f) * width + jj] += (1.f - w) * v;
-        base[(k * T + c) * width + jj] += w * v;
+        const float v = red[s * stride + k * 9 + j];
+        if ((int)ff == fr) acc += (1.f - w) * v;
+        if ((int)cfl == fr) acc += w * v;
       }
+      if (j < 3) a.g.v_transls[(k * T + fr) * 3 + j] = acc;
+      else a.g.v_rots[(k * T + fr) * 6 + j - 3] = acc;
     }
     // v_times[s] = dL/dw = sum_kj (base_c - base_f) * v_Bs
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    if (gtid < S) {
+      const int s = gtid;
       const float t = a.in.times[s];
       const float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));
       const float cfl = fminf(fmaxf(ceilf(t), 0.f), (float)(T - 1));
@@ -453,16 +450,15 @@ __global__ void __launch_bounds__(256) k_finish(const BwdArgs a, const float *re
       if (a.g.v_times) a.g.v_times[s] = acc;
     }
   }
-  if (a.g.v_RTs)
-    for (int idx = threadIdx.x; idx < S * 12; idx += blockDim.x) {
-      const int s = idx / 12, r = idx - s * 12;
-      a.g.v_RTs[idx] = red[s * stride + nk + r];
-    }
-  if (a.g.v_viewmat && threadIdx.x < 16) {
-    const int r = threadIdx.x / 4, c = threadIdx.x % 4;
+  if (a.g.v_RTs && gtid < S * 12) {
+    const int s = gtid / 12, r = gtid - s * 12;
+    a.g.v_RTs[gtid] = red[s * stride + nk + r];
+  }
+  if (a.g.v_viewmat && gtid < 16) {
+    const int r = gtid / 4, c = gtid % 4;
     float v = 0.f;
     if (r < 3) v = c < 3 ? red[S * stride + r * 3 + c] : red[S * stride + 9 + r];
-    a.g.v_viewmat[threadIdx.x] = v;
+    a.g.v_viewmat[gtid] = v;
   }
 }
 
@@ -504,8 +500,8 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   a.n_shared = n_shared_of(dims);
   const int K = dims->G > 0 ? dims->K : 0;
   const int KP = K | 1;
-  size_t lds = sizeof(float) * ((((size_t)dims->S * K * 9 + 3) & ~(size_t)3) + 2 * (size_t)BLK * KP + (size_t)BLK * NV +
-                                4 * ((size_t)K * 9 + 13));
+  size_t lds = sizeof(float) * ((((size_t)dims->S * K * 9 + 3) & ~(size_t)3) + 2 * (size_t)BLK * KP +
+                                8 * ((size_t)K * 9 + 13));
   if (lds > 160 * 1024) {
     d4gs_set_error("project_bwd: LDS budget exceeded (S=%d K=%d)", dims->S, dims->K);
     return D4GS_EINVAL;
@@ -519,6 +515,9 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   float *red = grads->partials + (size_t)blocks * a.n_shared;
   D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 3) / 4), dim3(256), 0, stream, grads->partials, blocks,
                      a.n_shared, red);
-  D4GS_LAUNCH("k_finish", k_finish, dim3(1), dim3(256), 0, stream, a, (const float *)red);
+  int fin = dims->G > 0 ? dims->K * dims->T * 9 : 0;
+  if (fin < dims->S * 12) fin = dims->S * 12;
+  if (fin < 16) fin = 16;
+  D4GS_LAUNCH("k_finish", k_finish, dim3((fin + 255) / 256), dim3(256), 0, stream, a, (const float *)red);
   return d4gs_check_launch("k_finish");
 }

@@ -57,6 +57,10 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
   const int g = blockIdx.x * D4GS_PROJ_BLOCK + tid;
   const Cam cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
   const bool dyn_block = (blockIdx.x * D4GS_PROJ_BLOCK) < G;
+  if (a.count_apart && a.out.tile_counts) {  // k_count_tiles (next in the stream) accumulates into a zeroed histogram: no memset node
+    const int n2 = 2 * S * a.tw * a.th;
+    for (int z = g; z < n2; z += gridDim.x * D4GS_PROJ_BLOCK) a.out.tile_counts[z] = 0;
+  }
   if (dyn_block) preblend_bases(a, Bs);
 
   const bool active = g < N;
@@ -260,8 +264,22 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(const int *in, int64
 
 // single block: exclusive scan of `n` ints in place (looping with a carry); optionally writes the total to
 // out[n] (int32) and to total64.
-__global__ void __launch_bounds__(1024) k_scan_single(const int *in, const int *in2, int *out, int64_t n, int write_last,
-                                                       int64_t *total64, int64_t *max64) {
+struct ScanJob {
+  const int *in, *in2;
+  int *out;
+  int64_t n;
+  int write_last;
+  int64_t *total64, *max64;
+};
+// gridDim.x = 2: block 0 runs job A, block 1 job B - the two single-block scans of the binning chain (block sums of the
+// instance scan; tile counts -> tile offsets) do not depend on each other, so they share one launch.
+__global__ void __launch_bounds__(1024) k_scan_single(const ScanJob ja, const ScanJob jb) {
+  const ScanJob &job = blockIdx.x ? jb : ja;
+  const int *in = job.in, *in2 = job.in2;
+  int *out = job.out;
+  const int64_t n = job.n;
+  const int write_last = job.write_last;
+  int64_t *total64 = job.total64, *max64 = job.max64;
   __shared__ int lds[20];
   __shared__ int smax;
   if (threadIdx.x == 0) smax = 0;
@@ -345,11 +363,6 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   const int64_t n_inst = (int64_t)dims->S * dims->N;
   const int64_t n_tiles = (int64_t)dims->S * a.tw * a.th;
-  hipError_t e = hipMemsetAsync(out->tile_counts, 0, sizeof(int32_t) * 2 * n_tiles, stream);
-  if (e != hipSuccess) {
-    d4gs_set_error("hipMemsetAsync(tile_counts): %s", hipGetErrorString(e));
-    return D4GS_ELAUNCH;
-  }
   size_t lds = 0;
   if (dims->G > 0) lds = sizeof(float) * (((size_t)dims->S * dims->K * 9 + 3) & ~(size_t)3) +
                          sizeof(float) * (size_t)dims->K * D4GS_PROJ_BLOCK;
@@ -361,6 +374,13 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   const size_t hist_bytes = sizeof(int) * (size_t)a.tw * a.th;
   static const bool force_in_kernel = getenv("D4GS_COUNT_IN_PROJECT") != nullptr;  // test hook for the fallback
   a.count_apart = hist_bytes <= 64 * 1024 && dims->N > 0 && !force_in_kernel;  // bigger tile grids: in-kernel atomics
+  if (!a.count_apart) {  // (count_apart: k_project_fwd zeroes the histogram itself, k_count_tiles fills it afterwards)
+    hipError_t e = hipMemsetAsync(out->tile_counts, 0, sizeof(int32_t) * 2 * n_tiles, stream);
+    if (e != hipSuccess) {
+      d4gs_set_error("hipMemsetAsync(tile_counts): %s", hipGetErrorString(e));
+      return D4GS_ELAUNCH;
+    }
+  }
   D4GS_LAUNCH("k_project_fwd", k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
   int rc = d4gs_check_launch("k_project_fwd");
   if (rc) return rc;
@@ -376,11 +396,10 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   const int sblocks = (int)((n_inst + SCAN_TILE - 1) / SCAN_TILE);
   D4GS_LAUNCH("k_scan_sums", k_scan_sums, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, n_inst,
                      out->scan_ws);
-  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->scan_ws, (const int *)nullptr, out->scan_ws, (int64_t)sblocks, 0,
-                     out->n_isect, (int64_t *)nullptr);
+  const ScanJob jsums{out->scan_ws, nullptr, out->scan_ws, (int64_t)sblocks, 0, out->n_isect, nullptr};
+  const ScanJob jtiles{out->tile_counts, out->tile_counts + n_tiles, out->tile_offsets, (int64_t)n_tiles, 1, nullptr, out->n_isect + 1};
+  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(2), dim3(1024), 0, stream, jsums, jtiles);
   D4GS_LAUNCH("k_scan_apply", k_scan_apply, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, out->scan_ws,
                      n_inst, out->isect_offsets);
-  D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(1), dim3(1024), 0, stream, out->tile_counts, (const int *)(out->tile_counts + n_tiles), out->tile_offsets, n_tiles, 1,
-                     (int64_t *)nullptr, out->n_isect + 1);
   return d4gs_check_launch("scan");
 }
