@@ -71,6 +71,11 @@ def parse():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md section 3's whole plan (cfg1 x 20 iterations, cfg2 x 3, torch and scalar C); minutes")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--sync-size-check", action="store_true",
+                    help="every render waits on the host for its intersection counts before the backward is issued (the "
+                         "library's default); without the flag the counts are verified once per step behind the launches "
+                         "(`deferred_size_check` + `engine.check_deferred()`, as examples/train_dynamic_step.py does), so "
+                         "the host may run a frame ahead and a slow host does not stall the GPU")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step (render forward + backward, deferred size check) in a HIP graph and time its "
                          "replays; single GPU only")
@@ -277,6 +282,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from deblur4dgs_amd import _lib as L
+    from deblur4dgs_amd import engine
     from deblur4dgs_amd.exposure import render_exposure
     from deblur4dgs_amd.parallel import ShardedExposure
 
@@ -312,7 +318,11 @@ def main():
         sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0, channels=channels,
                                                 scale_mul=args.scale_mul)
         sharder = ShardedExposure(world, rank, mode=mode) if use_dist else None
+        deferred = not args.sync_size_check
+        if sharder is not None:
+            sharder.deferred_size_check = deferred
         last = {}
+        mode_flag = {"deferred": deferred}
 
         def step():
             for v in leaves.values():
@@ -321,12 +331,14 @@ def main():
                 res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                       leaves["colors"], 3, leaves.get("motion_coefs"), leaves.get("rots"),
                                       leaves.get("transls"), leaves.get("times"), leaves["RTs"], leaves["viewmat"], d["K"],
-                                      W, H, background=bg, return_depth=True)
+                                      W, H, background=bg, return_depth=True, deferred_size_check=mode_flag["deferred"])
                 loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
                 loss.backward()
                 last["st"] = res["state"]
             else:
                 last["st"] = sharder.step(leaves, d["K"], W, H, bg, wimg, wacc)
+            if mode_flag["deferred"]:
+                engine.check_deferred()  # this step's list sizes, verified behind its launches (raises on overflow)
 
         for _ in range(warmup):
             step()
@@ -381,6 +393,12 @@ def main():
                 step()
             sync()
             kern_all = collect()
+        if deferred and not args.graph:  # one untimed step with the host-checked sizes: its state carries the EXACT counts
+            mode_flag["deferred"] = False  # (a deferred state only knows its capacities) for the byte / pair accounting
+            if sharder is not None:
+                sharder.deferred_size_check = False
+            step()
+            sync()
         if use_dist:
             import torch.distributed as dist
 
@@ -407,6 +425,8 @@ def main():
                     if not views_primary else f"views sharded x{world} (data parallel), RCCL gradient all-reduce")},
         "instances_per_s": value * S,
     }
+    out["config"]["size_check"] = ("host waits for every render's intersection counts" if args.sync_size_check else
+                                   "intersection counts verified once per step behind the launches (deferred)")
     if args.graph:
         out["config"]["launch"] = "one HIP graph per step (render forward + backward captured, deferred size check)"
     if world > 1 and not views_primary:  # secondary: data-parallel over camera views (weak scaling), same protocol

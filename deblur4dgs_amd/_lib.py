@@ -157,3 +157,21 @@ def fill(struct, **tensors):
     for k, v in tensors.items():
         setattr(struct, k, ptr(v))
     return struct
+
+
+_RAW_STREAM = None
+
+
+def raw_stream(index=None) -> int:
+    """The current HIP stream of device `index` (default: the current device) as an integer handle.  One C call:
+    torch.cuda.current_stream() builds a Python Stream object every time (~12 us, six times per rendered frame)."""
+    global _RAW_STREAM
+    import torch
+
+    if _RAW_STREAM is None:
+        _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if index is None:
+        index = torch.cuda.current_device()
+    if _RAW_STREAM:
+        return _RAW_STREAM(index)
+    return torch.cuda.current_stream(index).cuda_stream

@@ -101,8 +101,11 @@ def channel_chunks(D: int) -> list[tuple[int, int, int]]:
     return out
 
 
+raw_stream = L.raw_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(raw_stream())
 
 
 # (device, S, W, H, N bucket) -> (list capacity, bound on the longest tile list).  N is bucketed to its two leading bits
@@ -148,6 +151,9 @@ def _guess_put(key, val):
 _DEFERRED: dict = {}  # size key -> (pinned int64[2], event, capacity, max-tile hint) of the last unchecked render
 
 
+_PINNED_FREE: list = []  # pinned int64[2] buffers whose deferred count has been consumed (guarded by _SIZE_LOCK)
+
+
 def _deferred_poll(key, block: bool = False):
     """Look at the count of the previous deferred render of this shape, if it has arrived.  -> (n, max_tile) | None."""
     with _SIZE_LOCK:
@@ -161,6 +167,9 @@ def _deferred_poll(key, block: bool = False):
     with _SIZE_LOCK:
         _DEFERRED.pop(key, None)
     n, max_tile = host_n.tolist()
+    with _SIZE_LOCK:  # the copy has landed and been read: the pinned pair can carry the next count
+        if len(_PINNED_FREE) < 64:
+            _PINNED_FREE.append(host_n)
     _guess_put(key, (n + n // 4 + 4096, _sort_class(max_tile)))
     if n > cap or (hint > 0 and max_tile > hint):
         raise RuntimeError(f"deblur4dgs_amd: a render with deferred_size_check needed {n} intersections (longest tile "
@@ -179,7 +188,7 @@ def check_deferred():
 def _pinned_counts(dev):
     """One pinned int64[2] per (thread, device, stream): every use is followed by an event wait before the next one on
     that stream, and two streams of one thread never share a buffer."""
-    k = (threading.get_ident(), dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    k = (threading.get_ident(), dev.index, raw_stream(dev.index))
     with _SIZE_LOCK:
         if k not in _PINNED:
             if len(_PINNED) > 256:
@@ -358,7 +367,10 @@ class RasterFn(torch.autograd.Function):
             # the launches and is looked at by the next call (not under stream capture: a graph replays this shape).
             launch(*guess)
             if not capturing:
-                host_n = torch.empty(2, dtype=torch.int64).pin_memory()
+                with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
+                    host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
+                if host_n is None:
+                    host_n = torch.empty(2, dtype=torch.int64).pin_memory()
                 host_n.copy_(st.proj_out["n_isect"], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()

@@ -31,7 +31,7 @@ class PhotometricFn(torch.autograd.Function):
         nb = lib.d4gs_photometric_blocks(B, H, W)
         maps = torch.empty(B, H - 10, W - 10, 3, 3, device=p.device, dtype=torch.float32)
         scratch = torch.empty(2 * nb + 3, device=p.device, dtype=torch.float32)
-        stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+        stream = C.c_void_p(L.raw_stream(p.device.index))
         L.check(lib.d4gs_photometric_fwd(_p(p), _p(g), _p(m), B, H, W, Cc, w_l1, w_ssim, _p(maps), _p(scratch),
                                          _p(scratch[2 * nb:]), stream), "d4gs_photometric_fwd")
         ctx.keep = (p, g, m, maps)
@@ -45,7 +45,7 @@ class PhotometricFn(torch.autograd.Function):
         B, H, W, Cc = p.shape
         v = v_loss.detach().float().reshape(1).contiguous()
         out = torch.empty_like(p)
-        stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+        stream = C.c_void_p(L.raw_stream(p.device.index))
         L.check(L.lib().d4gs_photometric_bwd(_p(p), _p(g), _p(m), _p(maps), _p(v), B, H, W, Cc, ctx.w[0], ctx.w[1], _p(out),
                                              stream), "d4gs_photometric_bwd")
         return out, None, None, None, None

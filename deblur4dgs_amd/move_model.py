@@ -34,7 +34,9 @@ def _need_gpu(t: torch.Tensor):
 
 # ------------------------------------------------------------------ fused HIP path (csrc/camera.hip)
 def _stream(t):
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    from . import _lib as L
+
+    return C.c_void_p(L.raw_stream(t.device.index))
 
 
 def _p(t):
