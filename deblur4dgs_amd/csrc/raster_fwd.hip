@@ -367,7 +367,10 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
      const int i1 = min(i0 + 16, imax);
      for (int i = i0; i < i1; i++) {
       const bool act = i < cnt;
-      const int j = act ? (int)mylist[i] : 0;
+      // the byte is read unconditionally (no divergent branch in the loop; i < FB stays inside the row's list) and
+      // replaced by staged splat 0 past the row's count: a stale index could point at a never-staged record (NaN * 0)
+      const int jr = (int)mylist[i];
+      const int j = act ? jr : 0;
       const float4 g0 = sg0[j], g1 = sg1[j];
       const float dx = g0.x - pxf, dy = g0.y - pyf;
       const float sigma = splat_sigma2(g1, dx, dy);  // sigma * log2(e)
