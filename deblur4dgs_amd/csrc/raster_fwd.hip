@@ -363,6 +363,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
     __builtin_amdgcn_wave_barrier();
     const int cnt = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
     const int imax = max(max(c0, c1), max(c2, c3));
+    int lastj = -1;
     for (int i0 = 0; i0 < imax; i0 += 16) {  // every 16 iterations: is the whole wave saturated?
      const int i1 = min(i0 + 16, imax);
      for (int i = i0; i < i1; i++) {
@@ -377,9 +378,9 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
       const float alpha = fminf(0.999f, g0.z * __builtin_amdgcn_exp2f(-sigma));
       bool valid = act && !done && (sigma >= 0.f) && (alpha >= (1.f / 255.f));
       const float nT = T * (1.f - alpha);
-      const bool stop = valid && (nT <= 1e-4f);
-      done = done || stop;
-      valid = valid && !stop;
+      const bool sat = nT <= 1e-4f;  // one compare feeds both masks
+      done = done || (valid && sat);
+      valid = valid && !sat;
       const float vis = valid ? alpha * T : 0.f;
 #pragma unroll
       for (int v = 0; v < DV; v++) {
@@ -391,10 +392,11 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
       }
       if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
       T = valid ? nT : T;
-      last = valid ? (b + j) : last;
+      lastj = valid ? j : lastj;
      }
      if (__all(done)) break;
     }
+    last = lastj >= 0 ? b + lastj : last;  // list index of the batch's last contributor, formed once per batch
   }
 
   if (inside) {
