@@ -78,7 +78,7 @@ def parse():
                          "the host may run a frame ahead and a slow host does not stall the GPU")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step (render forward + backward, deferred size check) in a HIP graph and time its "
-                         "replays; single GPU only")
+                         "replays (with --gpus N > 1 / --force-dist the RCCL collectives are captured too: verified at world size 1 only)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL code path with world_size 1")
     return ap.parse_args()
 
@@ -343,12 +343,22 @@ def main():
         for _ in range(warmup):
             step()
         sync()
-        if args.graph and sharder is None:  # same kernels, same arithmetic; one hipGraphLaunch per step.  (Capturing the
-            # sharded step with its RCCL collectives faulted the GPU in a world-size-1 trial - not offered.)
+        if args.graph:  # same kernels, same arithmetic; one hipGraphLaunch per step.  The sharded step is captured with its
+            # RCCL collectives (verified at world size 1 only: tests/test_gpu_parallel.py - the pool has 1-GPU boxes).
+            mode_flag["deferred"] = False  # one host-checked eager step: its state carries the exact list sizes
+            if sharder is not None:
+                sharder.deferred_size_check = False
+            step()
+            sync()
+            real_state = last["st"]
+            mode_flag["deferred"] = deferred
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
 
             def gstep():
+                if sharder is not None:
+                    sharder.deferred_size_check = True
+                    return sharder.step(leaves, d["K"], W, H, bg, wimg, wacc)
                 for v in leaves.values():
                     v.grad = None
                 res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
@@ -363,12 +373,12 @@ def main():
                 for _ in range(2):
                     gstep()
             torch.cuda.current_stream().wait_stream(side)
-            for v in leaves.values():
-                v.grad = None
+            if sharder is None:
+                for v in leaves.values():
+                    v.grad = None
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 gstep()
-            real_state = last["st"]
 
             def step():  # noqa: F811
                 graph.replay()
@@ -428,7 +438,8 @@ def main():
     out["config"]["size_check"] = ("host waits for every render's intersection counts" if args.sync_size_check else
                                    "intersection counts verified once per step behind the launches (deferred)")
     if args.graph:
-        out["config"]["launch"] = "one HIP graph per step (render forward + backward captured, deferred size check)"
+        out["config"]["launch"] = ("one HIP graph per step (render forward + backward" + (" + RCCL collectives" if use_dist else "")
+                                   + " captured, deferred size check)")
     if world > 1 and not views_primary:  # secondary: data-parallel over camera views (weak scaling), same protocol
         dt_v, _, _, _, _ = measure("views", args.steps, args.warmup, False)
         out["views_weak_scaling"] = {"value": world * N / (dt_v / args.steps), "unit": "Gaussians/s", "scaling": "weak",
