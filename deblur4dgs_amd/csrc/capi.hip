@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdint.h>
+
 #include "common.h"
 
 int d4gs_project_fwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, hipStream_t);
@@ -224,6 +226,10 @@ int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
   if (!r || !r->render_colors || !r->render_alphas || !r->last_ids || !r->final_T || !g || !g->v_render_colors ||
       !g->isect_grad || !g->v_means2d || !g->v_conics || !g->v_depths || !g->v_opac_act || !g->v_ctab) {
     d4gs_set_error("d4gs_raster_bwd: NULL forward state or gradient buffer");
+    return D4GS_EINVAL;
+  }
+  if (((uintptr_t)g->isect_grad & 15) != 0) {  // k_gather streams the rows as 16-byte words
+    d4gs_set_error("d4gs_raster_bwd: isect_grad must be 16-byte aligned");
     return D4GS_EINVAL;
   }
   if (g->stats_grad_norm_acc && (!g->stats_vis_count || !g->stats_max_radii || !proj->radii || g->stats_batch_size <= 0)) {

@@ -764,6 +764,7 @@ struct GatherArgs {
   const float *isect_grad;
   const int64_t *n_dev;  // see RasterBwdArgs: an overflowed render has no valid rows - its gradients are zeros
   int64_t cap, max_hint;
+  int64_t rows;  // rows of isect_grad the caller allocated (>= 1)
   float *v_means2d, *v_conics, *v_depths, *v_opac_act, *v_ctab;
   // fused densification statistics (trainer.py:967-989); stats_acc == nullptr: off
   const int32_t *radii;
@@ -783,7 +784,7 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int R = 6 + NCH;
-  __shared__ float stage[(GATHER_THREADS / 64) * GATHER_ROWS * R];
+  __shared__ __attribute__((aligned(16))) float stage[(GATHER_THREADS / 64) * GATHER_ROWS * R];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = g < a.N;
@@ -797,25 +798,40 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   float st_acc = 0.f, st_mr = 0.f;
   int64_t st_vis = 0;
   if (stats && in) st_acc = a.stats_acc[g], st_vis = a.stats_vis[g], st_mr = a.stats_mr[g];
+  // the (count, offset) pair of the next sub-sample is fetched while the current one is streamed and summed
+  const size_t gi = in ? g : a.N - 1;
+  int cnt_n = (in && !overflow) ? a.tiles_touched[gi] : 0, off_n = a.isect_offsets[gi];
   for (int s = 0; s < a.S; s++) {
-    const size_t i = (size_t)s * a.N + (in ? g : a.N - 1);
-    const int cnt = (in && !overflow) ? a.tiles_touched[i] : 0;
-    const int off = a.isect_offsets[i];
+    const size_t i = (size_t)s * a.N + gi;
+    const int cnt = cnt_n, off = off_n;
+    if (s + 1 < a.S) {
+      cnt_n = (in && !overflow) ? a.tiles_touched[i + a.N] : 0;
+      off_n = a.isect_offsets[i + a.N];
+    }
     // span of the wave: [first lane's offset, last lane's offset + count)
     const int base = __builtin_amdgcn_readfirstlane(off);
-    int endl = off + cnt;
+    int endl = overflow ? 0 : off + cnt;  // overflowed lists: the offsets index past the buffer - nothing is streamed
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) endl = max(endl, __shfl_xor(endl, o));
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.f;
     // the span is streamed in chunks of GATHER_ROWS rows; a lane's rows [off, off + cnt) are contiguous, so it adds
-    // the part of them that lies in the current chunk - always in ascending k, whatever the chunking
-    for (int cb = base; cb < endl; cb += GATHER_ROWS) {
+    // the part of them that lies in the current chunk - always in ascending k, whatever the chunking.  The copy moves
+    // 16-byte words: the span start is rounded down to a row whose byte offset is a multiple of 16 (every APER-th row;
+    // GATHER_ROWS keeps the later chunks aligned) and the last word may carry up to 3 floats of the next row.
+    constexpr int APER = (R % 4 == 0) ? 1 : (R % 2 == 0) ? 2 : 4;
+    static_assert(GATHER_ROWS % APER == 0 && (GATHER_ROWS * R) % 4 == 0, "chunks must start on 16-byte words");
+    for (int cb = base & ~(APER - 1); cb < endl; cb += GATHER_ROWS) {
       const int ce = min(cb + GATHER_ROWS, endl);
-      const float *src = a.isect_grad + (size_t)cb * R;
-      const int nf = (ce - cb) * R;
-      for (int f = lane; f < nf; f += 64) mine[f] = src[f];
+      const float4 *src = reinterpret_cast<const float4 *>(a.isect_grad + (size_t)cb * R);
+      float4 *dst4 = reinterpret_cast<float4 *>(mine);
+      // (the buffer holds a.rows rows: the last word of the last row must not be read past its end)
+      const int nf4 = (int)min((int64_t)((ce - cb) * R + 3) / 4, ((a.rows - cb) * (int64_t)R) / 4);
+      const int tail0 = nf4 * 4, tail1 = (ce - cb) * R;  // floats the word copy could not cover (end of the buffer)
+#pragma unroll 4
+      for (int f = lane; f < nf4; f += 64) dst4[f] = src[f];
+      if (tail0 + lane < tail1) mine[tail0 + lane] = a.isect_grad[(size_t)cb * R + tail0 + lane];
       __builtin_amdgcn_wave_barrier();
       const int k0 = max(off, cb), k1 = min(off + cnt, ce);
       const float *row = mine + (k0 - cb) * R;
@@ -902,6 +918,7 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
   GatherArgs ga;
   ga.n_dev = proj->n_isect, ga.cap = isect->n_isect, ga.max_hint = isect->max_tile_count;
+  ga.rows = isect->n_isect > 0 ? isect->n_isect : 1;
   ga.N = dims->N, ga.S = dims->S, ga.D = dims->D, ga.DP = (dims->D + 3) & ~3;
   ga.depth = dims->depth_mode != D4GS_DEPTH_NONE;
   ga.tiles_touched = proj->tiles_touched, ga.isect_offsets = proj->isect_offsets, ga.isect_grad = g->isect_grad;

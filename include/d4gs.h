@@ -132,7 +132,7 @@ typedef struct D4gsRaster {
 typedef struct D4gsRasterGrads {
   const float *v_render_colors; /* [S,H,W,D+depth] */
   const float *v_render_alphas; /* [S,H,W] or NULL */
-  float *isect_grad;            /* [n_isect, 6+D+depth] scratch (every row is written by the call) */
+  float *isect_grad;            /* [n_isect, 6+D+depth] scratch (every row is written by the call); 16-byte aligned */
   float *v_means2d;             /* [S,N,2]  (= means2d.grad contract, trainer.py:975) */
   float *v_conics;              /* [S,N,3] */
   float *v_depths;              /* [S,N]   (zeros when depth_mode == 0) */
