@@ -42,7 +42,7 @@ class Raster(C.Structure):
 
 
 class RasterGrads(C.Structure):
-    _fields_ = [(n, F) for n in ("v_render_colors", "v_render_alphas", "isect_grad", "v_means2d", "v_conics",
+    _fields_ = [(n, F) for n in ("v_render_colors", "v_render_alphas", "isect_grad", "isect_live", "v_means2d", "v_conics",
                                  "v_depths", "v_opac_act", "v_ctab", "stats_grad_norm_acc", "stats_vis_count",
                                  "stats_max_radii")] + [("stats_batch_size", C.c_int32), ("stats_update_max_radii", C.c_int32)]
 
@@ -134,8 +134,8 @@ def lib() -> C.CDLL:
                                            C.c_float, vp, vp]
         L.d4gs_blend_fwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp]
         L.d4gs_blend_bwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp, vp, vp]
-        if L.d4gs_version() != 200:
-            raise RuntimeError(f"libd4gs.so version {L.d4gs_version()} != 200 (stale build?)")
+        if L.d4gs_version() != 201:
+            raise RuntimeError(f"libd4gs.so version {L.d4gs_version()} != 201 (stale build?)")
         _lib = L
     return _lib
 

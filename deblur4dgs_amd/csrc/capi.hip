@@ -224,7 +224,7 @@ int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
   if (rc) return rc;
   if ((rc = check_binned("d4gs_raster_bwd", proj, isect))) return rc;
   if (!r || !r->render_colors || !r->render_alphas || !r->last_ids || !r->final_T || !g || !g->v_render_colors ||
-      !g->isect_grad || !g->v_means2d || !g->v_conics || !g->v_depths || !g->v_opac_act || !g->v_ctab) {
+      !g->isect_grad || !g->isect_live || !g->v_means2d || !g->v_conics || !g->v_depths || !g->v_opac_act || !g->v_ctab) {
     d4gs_set_error("d4gs_raster_bwd: NULL forward state or gradient buffer");
     return D4GS_EINVAL;
   }

@@ -33,6 +33,8 @@ struct RasterBwdArgs {
   const float *v_out;
   const float *v_alphas;  // may be null
   float *isect_grad;
+  uint8_t *live;         // [cap] 1 = row written.  Sparse mode: variant B marks the rows it replays (buffer zeroed first)
+  int sparse;            // 0: every row is written (rows behind a tile's last contributor are zero-filled), no flags
   const int64_t *n_dev;  // device {total, longest list}; the lists were sized for (cap, max_hint) - see binning.hip
   int64_t cap, max_hint;
 };
@@ -345,12 +347,15 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
   };
-  // rows behind the tile's last contributor are never replayed: zero them here (no whole-buffer memset needed)
-  for (int idx = hi + 1 + tid; idx < end; idx += 256) {
-    float *dst = a.isect_grad + (size_t)a.sorted_emit[idx] * R;
+  // Rows behind the tile's last contributor are never replayed.  Dense mode zero-fills them here (no whole-buffer
+  // memset); sparse mode leaves them unwritten - their `live` byte stays 0 and k_gather skips them: in occluded /
+  // large-footprint scenes that is most rows and zero-filling them costs more than the replay itself.
+  if (!a.sparse)
+    for (int idx = hi + 1 + tid; idx < end; idx += 256) {
+      float *dst = a.isect_grad + (size_t)a.sorted_emit[idx] * R;
 #pragma unroll
-    for (int r = 0; r < R; r++) dst[r] = 0.f;
-  }
+      for (int r = 0; r < R; r++) dst[r] = 0.f;
+    }
 
   for (int bh = hi; bh >= start; bh -= NB) {
     __syncthreads();
@@ -493,6 +498,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
       dst[5] = -sum[5] * g1.w;
 #pragma unroll
       for (int c = 0; c < NCH; c++) dst[6 + c] = sum[6 + c];
+      if (a.sparse) a.live[emit] = 1;
     }
   }
 }
@@ -765,6 +771,8 @@ struct GatherArgs {
   const int64_t *n_dev;  // see RasterBwdArgs: an overflowed render has no valid rows - its gradients are zeros
   int64_t cap, max_hint;
   int64_t rows;  // rows of isect_grad the caller allocated (>= 1)
+  const uint8_t *live;  // [rows] 1 = the row was written by the composite backward (sparse mode)
+  int sparse;
   float *v_means2d, *v_conics, *v_depths, *v_opac_act, *v_ctab;
   // fused densification statistics (trainer.py:967-989); stats_acc == nullptr: off
   const int32_t *radii;
@@ -779,16 +787,20 @@ struct GatherArgs {
 // isect_grad: the wave streams it into LDS with coalesced loads and every lane then sums its own rows from there, in
 // the same k order as a direct read (bit-identical).  Spans longer than the LDS budget (wide splats) take several chunks.
 constexpr int GATHER_THREADS = 128, GATHER_ROWS = 192;  // rows of LDS per wave
-template <int D, bool DEPTH>
+template <int D, bool DEPTH, bool SPARSE>
 __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int R = 6 + NCH;
   __shared__ __attribute__((aligned(16))) float stage[(GATHER_THREADS / 64) * GATHER_ROWS * R];
+  __shared__ uint32_t slive[SPARSE ? (GATHER_THREADS / 64) * 64 : 1];  // flags of a chunk as 4-byte words (<= GATHER_ROWS + 3 bytes)
+  static_assert(GATHER_ROWS + 6 <= 256, "one flag word per lane");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = g < a.N;
   float *mine = stage + wv * GATHER_ROWS * R;
+  uint32_t *mylive32 = slive + (SPARSE ? wv * 64 : 0);
+  const uint8_t *mylive = reinterpret_cast<const uint8_t *>(mylive32);
   float vo = 0.f, vc[D];
 #pragma unroll
   for (int c = 0; c < D; c++) vc[c] = 0.f;
@@ -824,6 +836,11 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
     static_assert(GATHER_ROWS % APER == 0 && (GATHER_ROWS * R) % 4 == 0, "chunks must start on 16-byte words");
     for (int cb = base & ~(APER - 1); cb < endl; cb += GATHER_ROWS) {
       const int ce = min(cb + GATHER_ROWS, endl);
+      // the chunk's flag bytes, fetched as words BEFORE the rows so that their latency hides behind the row stream
+      const int fb = cb & ~3;
+      uint32_t fl = 0u;
+      if constexpr (SPARSE)
+        if (lane < ((ce - fb + 3) >> 2)) fl = reinterpret_cast<const uint32_t *>(a.live)[(fb >> 2) + lane];
       const float4 *src = reinterpret_cast<const float4 *>(a.isect_grad + (size_t)cb * R);
       float4 *dst4 = reinterpret_cast<float4 *>(mine);
       // (the buffer holds a.rows rows: the last word of the last row must not be read past its end)
@@ -832,10 +849,13 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
 #pragma unroll 4
       for (int f = lane; f < nf4; f += 64) dst4[f] = src[f];
       if (tail0 + lane < tail1) mine[tail0 + lane] = a.isect_grad[(size_t)cb * R + tail0 + lane];
+      if constexpr (SPARSE) mylive32[lane] = fl;
       __builtin_amdgcn_wave_barrier();
       const int k0 = max(off, cb), k1 = min(off + cnt, ce);
       const float *row = mine + (k0 - cb) * R;
       for (int k = k0; k < k1; k++, row += R) {
+        if constexpr (SPARSE)
+          if (!mylive[k - fb]) continue;  // never written (behind its tile's last contributor): the bytes are stale
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] += row[r];
       }
@@ -872,14 +892,32 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   for (int c = 0; c < DP; c++) a.v_ctab[(size_t)g * DP + c] = c < D ? vc[c < D ? c : 0] : 0.f;
 }
 
+// Sparse rows pay when most rows are dead, which goes with large footprints: the rows per (sub-sample, Gaussian) instance
+// the lists were sized for is what the host knows without a round trip.  Measured: 1.8 rows per
+// instance -> dense is 3 % faster; 7.4 -> sparse is 13 % faster.  D4GS_BWD_ROWS=dense|sparse overrides.
+static bool choose_sparse(int64_t n_isect, int64_t n_inst) {
+  const char *force = getenv("D4GS_BWD_ROWS");  // read per launch: tests switch it inside one process
+  if (force && force[0] == 'd') return false;
+  if (force && force[0] == 's') return true;
+  return n_isect >= 6 * (n_inst > 0 ? n_inst : 1);
+}
+
 template <int D, bool DEPTH>
-int launch_bwd(const RasterBwdArgs &a, const GatherArgs &ga, int64_t n_isect, hipStream_t stream) {
+int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, hipStream_t stream) {
   constexpr int R = 6 + D + (DEPTH ? 1 : 0);
   static const bool wave_per_tile = getenv("D4GS_BWD_WAVE_PER_TILE") != nullptr;  // variant A, kept for A/B tests
+  a.sparse = ga.sparse = (!wave_per_tile && getenv("D4GS_BWD_MFMA") == nullptr && choose_sparse(n_isect, (int64_t)a.S * a.N)) ? 1 : 0;
   if (wave_per_tile) {  // variant A relies on a zeroed buffer; variant B zero-fills what it does not replay itself
     hipError_t e = hipMemsetAsync(a.isect_grad, 0, sizeof(float) * (size_t)R * (size_t)(n_isect > 0 ? n_isect : 1), stream);
     if (e != hipSuccess) {
       d4gs_set_error("hipMemsetAsync(isect_grad): %s", hipGetErrorString(e));
+      return D4GS_ELAUNCH;
+    }
+  }
+  if (a.sparse) {  // variant B marks the rows it writes
+    hipError_t e = hipMemsetAsync(a.live, 0, (((size_t)(n_isect > 0 ? n_isect : 1)) + 3) & ~(size_t)3, stream);
+    if (e != hipSuccess) {
+      d4gs_set_error("hipMemsetAsync(isect_live): %s", hipGetErrorString(e));
       return D4GS_ELAUNCH;
     }
   }
@@ -898,7 +936,10 @@ int launch_bwd(const RasterBwdArgs &a, const GatherArgs &ga, int64_t n_isect, hi
     int rc = d4gs_check_launch("k_raster_bwd");
     if (rc) return rc;
   }
-  D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH>), dim3((ga.N + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, stream, ga);
+  if (ga.sparse)
+    D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH, true>), dim3((ga.N + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, stream, ga);
+  else
+    D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH, false>), dim3((ga.N + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, stream, ga);
   return d4gs_check_launch("k_gather");
 }
 
@@ -914,11 +955,12 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.geom = proj->geom, a.ctab = proj->ctab, a.background = r->background;
   a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid, a.sorted_emit = isect->sorted_emit;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
-  a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad;
+  a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad, a.live = g->isect_live;
   a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
   GatherArgs ga;
   ga.n_dev = proj->n_isect, ga.cap = isect->n_isect, ga.max_hint = isect->max_tile_count;
   ga.rows = isect->n_isect > 0 ? isect->n_isect : 1;
+  ga.live = g->isect_live;
   ga.N = dims->N, ga.S = dims->S, ga.D = dims->D, ga.DP = (dims->D + 3) & ~3;
   ga.depth = dims->depth_mode != D4GS_DEPTH_NONE;
   ga.tiles_touched = proj->tiles_touched, ga.isect_offsets = proj->isect_offsets, ga.isect_grad = g->isect_grad;

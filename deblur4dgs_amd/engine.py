@@ -419,6 +419,7 @@ class RasterFn(torch.autograd.Function):
         g = dict(
             v_render_colors=v_colors, v_render_alphas=v_alphas,
             isect_grad=torch.empty(max(st.n_isect, 1), 6 + cfg.NCH, **f32),
+            isect_live=torch.empty((max(st.n_isect, 1) + 3) // 4 * 4, dtype=torch.uint8, device=dev),
             v_means2d=torch.empty(S, N, 2, **f32), v_conics=torch.empty(S, N, 3, **f32),
             v_depths=torch.empty(S, N, **f32), v_opac_act=torch.empty(N, **f32), v_ctab=torch.empty(N, cfg.DP, **f32),
         )

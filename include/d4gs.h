@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D4GS_VERSION 200
+#define D4GS_VERSION 201
 #define D4GS_TILE 16
 #define D4GS_GEOM_STRIDE 8 /* floats per instance record: x, y, opacity, depth, conic a, b, c, pad */
 
@@ -132,7 +132,10 @@ typedef struct D4gsRaster {
 typedef struct D4gsRasterGrads {
   const float *v_render_colors; /* [S,H,W,D+depth] */
   const float *v_render_alphas; /* [S,H,W] or NULL */
-  float *isect_grad;            /* [n_isect, 6+D+depth] scratch (every row is written by the call); 16-byte aligned */
+  float *isect_grad;            /* [n_isect, 6+D+depth] scratch, 16-byte aligned: the row of every intersection that was
+                                   replayed (at or before its tile's last contributor); the other rows are NOT written */
+  uint8_t *isect_live;          /* [n_isect rounded up to a multiple of 4] scratch, 4-byte aligned: 1 = the row above was
+                                   written by this call, 0 = skip it */
   float *v_means2d;             /* [S,N,2]  (= means2d.grad contract, trainer.py:975) */
   float *v_conics;              /* [S,N,3] */
   float *v_depths;              /* [S,N]   (zeros when depth_mode == 0) */
@@ -181,7 +184,7 @@ typedef struct {
   int64_t means2d, depths, conics, radii, opac_act, ctab, geom, tile_rects, tiles_touched, isect_offsets;
   int64_t tile_counts, tile_offsets, n_isect, scan_ws;          /* D4gsProjOut */
   int64_t render_colors, render_alphas, last_ids, final_T;       /* D4gsRaster */
-  int64_t isect_grad_row;                                        /* floats per intersection in isect_grad */
+  int64_t isect_grad_row;                                        /* floats per intersection in isect_grad (isect_live: 1 byte) */
   int64_t bwd_partials;                                          /* D4gsLeafGrads.partials */
   int32_t tiles_x, tiles_y, channels;                            /* tile grid; D + depth channel */
 } D4gsSizes;

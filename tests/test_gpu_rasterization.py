@@ -140,6 +140,35 @@ def test_backward_is_deterministic():
         assert torch.equal(a, b)  # no float atomics anywhere -> bitwise reproducible
 
 
+@pytest.mark.parametrize("mode,D", [("RGB+ED", 3), ("RGB", 8), ("RGB+ED", 16)])
+def test_sparse_and_dense_gradient_rows_agree_bitwise(mode, D, monkeypatch):
+    """The composite backward either zero-fills the rows of intersections behind their tile's last contributor (dense)
+    or leaves them unwritten and flags the written ones (sparse, chosen for large footprints): an occluded scene -
+    opaque splats in front, most of the list dead - must give bit-identical gradients either way, and equal the oracle
+    (the dense path is what the parity tests above exercise at these sizes)."""
+    W, H, N = 96, 64, 3000
+    inp = static_inputs(N, W, H, seed=11, dtype=torch.float32, D=D, scale_mul=20.0)
+    inp["opac"] = torch.full_like(inp["opac"], 0.999)  # tile-sized opaque splats: every pixel saturates within a few
+    #                                                    entries, most of each list lies behind the last contributor
+    grads = {}
+    for rows in ("dense", "sparse"):
+        monkeypatch.setenv("D4GS_BWD_ROWS", rows)
+        rc, ra, info, tg = _run_gpu(inp, W, H, mode, torch.ones(D), requires_grad=True)
+        info["means2d"].retain_grad()
+        (rc.square().sum() + 0.5 * ra.sum()).backward()
+        torch.cuda.synchronize()
+        grads[rows] = [tg[k].grad.clone() for k in ("means", "quats", "scales", "opac", "colors", "V")] + [info["means2d"].grad.clone()]
+    # sanity: the scene has what the test is about - lists with a dead tail behind the tile's last contributor
+    offs = torch.cat([info["isect_offsets"].view(-1), torch.tensor([info["n_isect"]], device=rc.device, dtype=torch.int32)]).long()
+    tile_last = torch.nn.functional.max_pool2d(info["last_ids"].float().view(1, 1, H, W), 16, ceil_mode=True).view(-1).long()
+    n_list = offs[1:] - offs[:-1]
+    dead_rows = int(((offs[1:] - 1 - tile_last).clamp(min=0) * (n_list > 0)).sum())
+    assert dead_rows > 0.2 * info["n_isect"], (dead_rows, info["n_isect"])
+    for a, b in zip(grads["dense"], grads["sparse"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert float(grads["dense"][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("mode,D", [("RGB+ED", 3), ("RGB", 4), ("RGB+ED", 16)])
 def test_exact_cull_changes_nothing(mode, D):
     """D4GS_EXACT_CULL drops (tile, splat) pairs in which no pixel can pass alpha >= 1/255: the image and every
