@@ -228,9 +228,9 @@ int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
     d4gs_set_error("d4gs_raster_bwd: NULL forward state or gradient buffer");
     return D4GS_EINVAL;
   }
-  if (((uintptr_t)g->isect_grad & 15) != 0) {  // k_gather streams the rows as 16-byte words
-    d4gs_set_error("d4gs_raster_bwd: isect_grad must be 16-byte aligned");
-    return D4GS_EINVAL;
+  if (((uintptr_t)g->isect_grad & 15) != 0 || ((uintptr_t)g->isect_live & 3) != 0) {  // k_gather streams the rows as
+    d4gs_set_error("d4gs_raster_bwd: isect_grad must be 16-byte aligned, isect_live 4-byte aligned");  // 16-byte words,
+    return D4GS_EINVAL;                                                                           // the flags as 4-byte words
   }
   if (g->stats_grad_norm_acc && (!g->stats_vis_count || !g->stats_max_radii || !proj->radii || g->stats_batch_size <= 0)) {
     d4gs_set_error("d4gs_raster_bwd: fused statistics need vis_count, max_radii, radii and a positive batch size");

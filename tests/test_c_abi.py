@@ -43,6 +43,25 @@ def test_version_and_error_paths(lib):
     assert lib.d4gs_project_fwd(C.byref(d), None, None, None) == -1  # NULL required inputs
 
 
+def test_raster_bwd_rejects_misaligned_scratch_before_any_hip_call(lib):
+    """k_gather streams isect_grad as 16-byte words and isect_live as 4-byte words: the C ABI says so and checks it on
+    the host (fake addresses - nothing is dereferenced before the validation)."""
+    from deblur4dgs_amd import _lib as L
+
+    lib.d4gs_last_error.restype = C.c_char_p
+    d = L.Dims(N=10, G=0, K=0, T=0, S=1, D=3, width=16, height=16)
+    fake = 0x10000
+    pout = L.ProjOut(**{n: fake for n, _ in L.ProjOut._fields_})
+    isect = L.Isect(n_isect=4, max_tile_count=0, keys=fake, gid_of_emit=fake, sorted_gid=fake, sorted_emit=fake)
+    ras = L.Raster(**{n: fake for n, _ in L.Raster._fields_})
+    ok = dict(v_render_colors=fake, isect_grad=fake, isect_live=fake, v_means2d=fake, v_conics=fake, v_depths=fake,
+              v_opac_act=fake, v_ctab=fake)
+    for bad, word in ((dict(isect_grad=fake + 8), b"16-byte"), (dict(isect_live=fake + 2), b"4-byte"), (dict(isect_live=0), b"NULL")):
+        rg = L.RasterGrads(**{**ok, **bad})
+        assert lib.d4gs_raster_bwd(C.byref(d), C.byref(pout), C.byref(isect), C.byref(ras), C.byref(rg), None) == -1
+        assert word in lib.d4gs_last_error(), lib.d4gs_last_error()
+
+
 def test_struct_layouts_match_header():
     """ctypes mirrors must have exactly the fields of the C structs, in order."""
     from deblur4dgs_amd import _lib as L
