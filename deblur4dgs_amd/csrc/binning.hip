@@ -19,6 +19,9 @@ struct EmitArgs {
   const int32_t *tile_rects;
   const int32_t *tiles_touched;
   const int32_t *isect_offsets;
+  int32_t *isect_offsets_out;  // fused scan (d4gs_fused_scan_chunks): this kernel computes and writes the offsets
+  const int32_t *chunk_base;   // [S * nchunks] exclusive scan of k_count_tiles' chunk sums
+  int nchunks;                 // 0: offsets come from k_scan_apply
   int32_t *tile_cursor;  // tile_counts: [0,T) splats per tile, [T,2T) slot cursors (zero on entry)
   const int32_t *tile_offsets;
   uint64_t *keys;
@@ -82,6 +85,37 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
     }
     __syncthreads();
   }
+  // fused scan: emission index base of each of the block's 4096 instances = chunk base + exclusive scan of the counts in
+  // instance order (q-major, then lane) - exactly what k_scan_apply would have written
+  uint32_t ebase[EMIT_PER_THREAD];
+  if (a.nchunks) {
+    __shared__ int wsum[EMIT_THREADS / 64];
+    int carry = a.chunk_base[s * a.nchunks + chunk];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < EMIT_PER_THREAD; q++) {
+      int inc = cnt[q];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+      }
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      int base = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < EMIT_THREADS / 64; w++) {
+        const int x = wsum[w];
+        base += w < wave ? x : 0;
+        tot += x;
+      }
+      ebase[q] = (uint32_t)(carry + base + inc - cnt[q]);
+      carry += tot;
+      __syncthreads();
+      const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
+      if (g < a.d.N) a.isect_offsets_out[(int64_t)s * a.d.N + g] = (int32_t)ebase[q];
+    }
+  }
 #pragma unroll
   for (int q = 0; q < EMIT_PER_THREAD; q++) {
     if (cnt[q] == 0) continue;
@@ -89,7 +123,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
     const int64_t i = (int64_t)s * a.d.N + g;
     const int x0 = rx[q] & 0xffff, x1 = rx[q] >> 16, y0 = ry[q] & 0xffff, y1 = ry[q] >> 16;
     const uint64_t hi = (uint64_t)__float_as_uint(a.depths[i]) << 32;
-    uint32_t e = (uint32_t)a.isect_offsets[i];
+    uint32_t e = a.nchunks ? ebase[q] : (uint32_t)a.isect_offsets[i];
     for (int ty = y0; ty < y1; ty++)
       for (int tx = x0; tx < x1; tx++) {
         const int t = ty * a.tw + tx;
@@ -273,6 +307,7 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.tile_rects = proj->tile_rects;
   e.tiles_touched = proj->tiles_touched;
   e.isect_offsets = proj->isect_offsets;
+  e.isect_offsets_out = proj->isect_offsets, e.chunk_base = proj->scan_ws, e.nchunks = d4gs_fused_scan_chunks(dims);
   e.tile_cursor = proj->tile_counts;
   e.tile_offsets = proj->tile_offsets;
   e.keys = isect->keys;
@@ -281,6 +316,10 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   e.n_dev = proj->n_isect, e.cap = isect->n_isect, e.max_hint = isect->max_tile_count;
   const int per_block = EMIT_THREADS * EMIT_PER_THREAD;
+  if (e.nchunks && e.nchunks != (dims->N + per_block - 1) / per_block) {  // k_count_tiles' chunks must be this kernel's
+    d4gs_set_error("internal: fused scan chunking mismatch (%d vs %d)", e.nchunks, (dims->N + per_block - 1) / per_block);
+    return D4GS_EINVAL;
+  }
   const size_t bins_bytes = sizeof(int) * (size_t)e.tw * e.th;
   e.use_lds = bins_bytes <= 64 * 1024;
   D4GS_LAUNCH("k_emit", k_emit, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS),

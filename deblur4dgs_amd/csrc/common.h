@@ -197,6 +197,9 @@ __device__ __forceinline__ void project_instance(const Cam &cam, const float *mw
   o.radius = (int)radius;
 }
 
+// > 0: the fused scan is in effect for this configuration and this is its chunk count per sub-sample (project_fwd.hip)
+int d4gs_fused_scan_chunks(const D4gsDims *d);
+
 // Optional per-kernel HIP-event profiler (off by default; used by bench.py for the roofline object).
 struct ProfScope {
   int slot;

@@ -198,27 +198,42 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
 constexpr int COUNT_THREADS = 1024, COUNT_PER_THREAD = 4;
 __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__restrict__ tile_rects,
                                                               const int *__restrict__ tiles_touched, int N, int S, int tw,
-                                                              int th, int *__restrict__ tile_counts) {
+                                                              int th, int *__restrict__ tile_counts, int *__restrict__ chunk_sums) {
   extern __shared__ int hist[];  // [tiles]
+  __shared__ int wsum[COUNT_THREADS / 64];
   const int tiles = tw * th, tid = threadIdx.x;
   const int s = blockIdx.x % S, chunk = blockIdx.x / S;  // neighbouring blocks work on different sub-samples' counters
   for (int z = tid; z < tiles; z += COUNT_THREADS) hist[z] = 0;
   __syncthreads();
+  int touched = 0;  // this lane's share of the chunk's intersection count (fused scan: see d4gs_fused_scan)
 #pragma unroll
   for (int q = 0; q < COUNT_PER_THREAD; q++) {
     const int g = (chunk * COUNT_PER_THREAD + q) * COUNT_THREADS + tid;
     if (g >= N) continue;
     const size_t i = (size_t)s * N + g;
-    if (tiles_touched[i] == 0) continue;
+    const int tt = tiles_touched[i];
+    touched += tt;
+    if (tt == 0) continue;
     const int2 rc = *reinterpret_cast<const int2 *>(tile_rects + i * 2);
     const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
     for (int ty = y0; ty < y1; ty++)
       for (int tx = x0; tx < x1; tx++) atomicAdd(&hist[ty * tw + tx], 1);
   }
+  if (chunk_sums) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) touched += __shfl_xor(touched, o);
+    if ((tid & 63) == 0) wsum[tid >> 6] = touched;
+  }
   __syncthreads();
   for (int z = tid; z < tiles; z += COUNT_THREADS) {
     const int c = hist[z];
     if (c > 0) atomicAdd(tile_counts + (size_t)s * tiles + z, c);
+  }
+  if (chunk_sums && tid == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < COUNT_THREADS / 64; w++) t += wsum[w];
+    chunk_sums[(size_t)s * gridDim.x / S + chunk] = t;  // (sub-sample, chunk) order = the flat instance order
   }
 }
 
@@ -330,6 +345,21 @@ extern "C" size_t d4gs_scan_ws_elems(int64_t n_instances) {
   return (size_t)((n_instances + SCAN_TILE - 1) / SCAN_TILE) + 16;
 }
 
+// Fused scan of the per-instance intersection counts (small tile grids, i.e. every BASELINE config): k_count_tiles also
+// leaves the sum of each (sub-sample, 4096-instance chunk), one single-block scan turns the sums into chunk bases, and
+// k_emit - whose blocks are the same chunks - scans inside its chunk and writes isect_offsets itself: no k_scan_sums /
+// k_scan_apply launches.  Same flat order, same offsets.  Both d4gs_project_fwd and d4gs_bin_sort ask this predicate.
+int d4gs_fused_scan_chunks(const D4gsDims *d) {
+  static const bool force_in_kernel = getenv("D4GS_COUNT_IN_PROJECT") != nullptr;
+  static const bool off = getenv("D4GS_NO_FUSED_SCAN") != nullptr;  // A/B hook
+  const int tw = (d->width + D4GS_TILE - 1) / D4GS_TILE, th = (d->height + D4GS_TILE - 1) / D4GS_TILE;
+  if (off || force_in_kernel || d->N <= 0 || sizeof(int) * (size_t)tw * th > 64 * 1024) return 0;
+  const int per_block = COUNT_THREADS * COUNT_PER_THREAD;
+  const int64_t nchunks = (d->N + per_block - 1) / per_block;
+  if ((size_t)(nchunks * d->S) + 1 > d4gs_scan_ws_elems((int64_t)d->S * d->N)) return 0;  // tiny N, many sub-samples
+  return (int)nchunks;
+}
+
 static size_t fwd_lds_bytes(const D4gsDims *dims) {
   if (dims->G <= 0) return 0;
   return sizeof(float) * (((size_t)dims->S * dims->K * 9 + 3) & ~(size_t)3) + sizeof(float) * (size_t)dims->K * D4GS_PROJ_BLOCK;
@@ -374,6 +404,7 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   const size_t hist_bytes = sizeof(int) * (size_t)a.tw * a.th;
   static const bool force_in_kernel = getenv("D4GS_COUNT_IN_PROJECT") != nullptr;  // test hook for the fallback
   a.count_apart = hist_bytes <= 64 * 1024 && dims->N > 0 && !force_in_kernel;  // bigger tile grids: in-kernel atomics
+  const int fused_chunks = a.count_apart ? d4gs_fused_scan_chunks(dims) : 0;
   if (!a.count_apart) {  // (count_apart: k_project_fwd zeroes the histogram itself, k_count_tiles fills it afterwards)
     hipError_t e = hipMemsetAsync(out->tile_counts, 0, sizeof(int32_t) * 2 * n_tiles, stream);
     if (e != hipSuccess) {
@@ -389,17 +420,19 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
     const int cblocks = ((dims->N + per_block - 1) / per_block) * dims->S;
     D4GS_LAUNCH("k_count_tiles", k_count_tiles, dim3(cblocks), dim3(COUNT_THREADS), hist_bytes, stream,
                 (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th,
-                out->tile_counts);
+                out->tile_counts, fused_chunks ? out->scan_ws : (int *)nullptr);
     rc = d4gs_check_launch("k_count_tiles");
     if (rc) return rc;
   }
-  const int sblocks = (int)((n_inst + SCAN_TILE - 1) / SCAN_TILE);
-  D4GS_LAUNCH("k_scan_sums", k_scan_sums, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, n_inst,
-                     out->scan_ws);
+  const int sblocks = fused_chunks ? fused_chunks * dims->S : (int)((n_inst + SCAN_TILE - 1) / SCAN_TILE);
+  if (!fused_chunks)
+    D4GS_LAUNCH("k_scan_sums", k_scan_sums, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, n_inst,
+                       out->scan_ws);
   const ScanJob jsums{out->scan_ws, nullptr, out->scan_ws, (int64_t)sblocks, 0, out->n_isect, nullptr};
   const ScanJob jtiles{out->tile_counts, out->tile_counts + n_tiles, out->tile_offsets, (int64_t)n_tiles, 1, nullptr, out->n_isect + 1};
   D4GS_LAUNCH("k_scan_single", k_scan_single, dim3(2), dim3(1024), 0, stream, jsums, jtiles);
-  D4GS_LAUNCH("k_scan_apply", k_scan_apply, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, out->scan_ws,
-                     n_inst, out->isect_offsets);
+  if (!fused_chunks)  // (fused: k_emit writes isect_offsets)
+    D4GS_LAUNCH("k_scan_apply", k_scan_apply, dim3(sblocks), dim3(SCAN_THREADS), 0, stream, out->tiles_touched, out->scan_ws,
+                       n_inst, out->isect_offsets);
   return d4gs_check_launch("scan");
 }

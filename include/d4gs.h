@@ -92,7 +92,8 @@ typedef struct D4gsProjOut {
   float *geom;             /* [S*N,8] packed raster record */
   int32_t *tile_rects;     /* [S*N,2] packed tile rectangle: x0 | x1<<16 , y0 | y1<<16 (min incl., max excl.) */
   int32_t *tiles_touched;  /* [S*N] */
-  int32_t *isect_offsets;  /* [S*N] exclusive scan of tiles_touched */
+  int32_t *isect_offsets;  /* [S*N] exclusive scan of tiles_touched (emission index base of every instance); complete after
+                              d4gs_bin_sort: for small tile grids the binning stage finishes the scan itself */
   int32_t *tile_ranks;     /* unused since the slots are handed out inside d4gs_bin_sort (kept for layout; may be NULL) */
   int32_t *tile_counts;    /* [2*S*tiles]: [0,T) splats per tile, [T,2T) per-tile slot cursors - zeroed by
                               d4gs_project_fwd and consumed by d4gs_bin_sort, which therefore runs once per projection

@@ -508,3 +508,28 @@ def test_engine_allocations_match_query_sizes():
     for name in ("render_colors", "render_alphas", "last_ids", "final_T"):
         assert st.raster[name].numel() == getattr(z, name), name
     assert z.isect_grad_row == 6 + st.cfg.NCH and (z.tiles_x, z.tiles_y) == st.cfg.tiles
+
+
+@pytest.mark.parametrize("N,S", [(1234, 3), (9000, 2), (40, 5)])
+def test_emission_offsets_are_the_exclusive_scan_of_the_tile_counts(N, S):
+    """`isect_offsets` = exclusive scan of `tiles_touched` in flat (sub-sample, Gaussian) order, whichever kernels
+    produce it: for small tile grids k_count_tiles leaves chunk sums and k_emit scans inside its chunk (no scan
+    launches of its own); N = 9000 spans three 4096-instance chunks, N = 40 with S = 5 is the tiny-scene case."""
+    from deblur4dgs_amd.exposure import render_exposure
+    from deblur4dgs_amd.synth import make_scene
+
+    dev = torch.device("cuda:0")
+    G = N // 2
+    sc = make_scene(N, G, 3, S, 100, 70, seed=9)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
+    res = render_exposure(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], 3, t["motion_coefs"], t["rots"],
+                          t["transls"], t["times"], t["RTs"], t["viewmat"], t["K"], 100, 70, return_depth=True)
+    st = res["state"]
+    tt = st.proj_out["tiles_touched"].long()
+    want = torch.cumsum(tt, 0) - tt
+    assert torch.equal(st.proj_out["isect_offsets"].long(), want)
+    assert int(tt.sum()) == st.n_isect
+    # every emission index is used exactly once, by the Gaussian that owns it
+    n = st.n_isect
+    owner = torch.repeat_interleave(torch.arange(S * N, device=dev) % N, tt)
+    assert torch.equal(st.isect["gid_of_emit"][:n].long(), owner)
