@@ -18,6 +18,18 @@ def _free_port():
     return p
 
 
+def _by_value(items):
+    """Tensors cross the queue as numpy arrays (pickled by value).  A torch tensor is passed as a file descriptor the
+    receiver has to fetch from the SENDER - which has usually exited by then (ConnectionResetError / FileNotFoundError)."""
+    return tuple(x.numpy() if torch.is_tensor(x) else x for x in items)
+
+
+def _tensors(items):
+    import numpy as np
+
+    return tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in items)
+
+
 def _worker(rank, world, port, S, C, seed, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,7 +53,7 @@ def _worker(rank, world, port, S, C, seed, q):
     ((out * wb).sum() + (acc * wa).sum()).backward()
     leaves = {"scale": scale}
     FlatGradAllReduce(leaves).reduce(leaves)
-    q.put((rank, own, out.detach(), acc.detach(), loc.grad.clone(), la.grad.clone(), scale.grad.clone()))
+    q.put(_by_value((rank, own, out.detach(), acc.detach(), loc.grad.clone(), la.grad.clone(), scale.grad.clone())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,7 +68,7 @@ def test_sharded_blend_matches_reference_blend(world, S, C):
     procs = [ctx.Process(target=_worker, args=(r, world, port, S, C, 11, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [_tensors(q.get(timeout=120)) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -125,8 +137,8 @@ def _gather_worker(rank, world, port, S, C, seed, q):
     ((out * wb).sum() + (acc * wa).sum() + (stack * ws).sum()).backward()
     armed = red._work is not None
     red.reduce(leaves)
-    q.put((rank, own, out.detach(), acc.detach(), stack.detach(), loc.grad.clone(), la.grad.clone(), scale.grad.clone(),
-           means.grad.clone(), armed))
+    q.put(_by_value((rank, own, out.detach(), acc.detach(), stack.detach(), loc.grad.clone(), la.grad.clone(),
+                     scale.grad.clone(), means.grad.clone(), armed)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -142,7 +154,7 @@ def test_gather_blend_equals_the_single_process_blend_bitwise(world, S, C):
     procs = [ctx.Process(target=_gather_worker, args=(r, world, port, S, C, 13, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [_tensors(q.get(timeout=120)) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
