@@ -174,3 +174,34 @@ def test_leaves_are_version_checked_between_forward_and_backward():
             L[victim].add_(0.1)
         with pytest.raises(RuntimeError, match="modified by an inplace operation"):
             res["blended"].sum().backward()
+
+
+@pytest.mark.parametrize("S,H,W,Cn", [(5, 21, 30, 17), (5, 22, 32, 17), (1, 16, 16, 4), (8, 24, 36, 5), (3, 7, 9, 3)])
+def test_blend_kernels_match_the_reference_blend(S, H, W, Cn):
+    """d4gs_blend_fwd / _bwd against the literal restatement of scene_model.py:386-397 (oracle.scene.blend_exposure, fp64):
+    both code paths - 16-byte words when the pixel count is a multiple of 4, scalar otherwise - incl. the
+    max{raw_0..raw_{S-2}, mean} quirk, exact ties, S = 1, and the gradient routing to the first winner."""
+    from deblur4dgs_amd.exposure import BlendFn, reference_policy
+    from oracle import scene as oscene
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(S * 100 + Cn)
+    renders = torch.rand(S, H, W, Cn, generator=g)
+    if Cn > 3:
+        renders[:, 0, 0, 3] = 0.0          # exact ties on the max-policy channel
+        renders[S - 1, 1, 1, 3] = 5.0      # the last sub-sample holds the max: the reference sees the mean there
+    alphas = torch.rand(S, H, W, generator=g)
+    wb, wa = torch.randn(H, W, Cn, generator=g), torch.randn(H, W, generator=g)
+    r_ref, a_ref = renders.double().requires_grad_(), alphas.double().requires_grad_()
+    out_ref, acc_ref, _ = oscene.blend_exposure([r_ref[s][None] for s in range(S)], [a_ref[s][None] for s in range(S)],
+                                                single=(S == 1))
+    ((out_ref[0] * wb.double()).sum() + (acc_ref[0] * wa.double()).sum()).backward()
+    r, a = renders.to(dev).requires_grad_(), alphas.to(dev).requires_grad_()
+    out, acc = BlendFn.apply(r, a, reference_policy(Cn))
+    ((out * wb.to(dev)).sum() + (acc * wa.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    for name, got, want in (("out", out, out_ref[0]), ("acc", acc, acc_ref[0]), ("v_renders", r.grad, r_ref.grad),
+                            ("v_alphas", a.grad, a_ref.grad)):
+        assert float((got.detach().cpu().double() - want.detach()).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), name
+    # the routing is exact: a max / min channel's gradient lands on ONE sub-sample (or is spread as the mean's)
+    assert torch.equal(r.grad.cpu() != 0, r_ref.grad != 0)
