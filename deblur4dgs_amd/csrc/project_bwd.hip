@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
   float *cf = Bs + nBs;              // [BLK][KP]   softmaxed coefficients
   float *vcf = cf + BLK * KP;        // [BLK][KP]   their gradients, summed over s
   float *psum = vcf + BLK * KP;       // [2][4][9K+13]  per-wave segment sums (+ dump slot), double-buffered over s
+  float *svec = psum + 8 * (9 * K + 13);  // [BLK][9]  this sub-sample's (v_transl 3, v_r6 6) of every lane: MFMA B operand
   const int tid = threadIdx.x;
   const int g = blockIdx.x * BLK + tid;
   const Cam cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
       float *pb = psum + (s & 1) * 4 * nop;
       float *mine = pb + seg * nop;
       if (dyn) {
-        if (dyn_block) {
+        if (dyn_block && K <= 8) {  // few bases: K x (9 multiplies + a 9-value wave reduction) on the VALU
           for (int k = 0; k < K; k++) {
             const float c = cf[tid * KP + k];
             float p[9];
@@ -324,6 +325,36 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
             for (int jj = 0; jj < 9; jj++) p[jj] = c * vec[jj];
             wave_sum_store(p, mine + k * 9, lane);
           }
+        } else if (dyn_block) {
+          // v_Bs[k][j] = sum over the wave's 64 Gaussians of coef[g][k] * vec[g][j]: a [K x 64] x [64 x 9] product.  On the
+          // matrix pipe: 16 v_mfma_f32_16x16x4_f32 per 16 bases (A = coefficients, B = vec, both read from LDS in the
+          // operand layout); exact f32, fixed order.  Measured (MI355X): K = 6 167 vs 158 us on the VALU (10 of the 16
+          // rows idle, a dependent MFMA chain at 2 waves per SIMD), K = 12 1011 vs 1095, K = 20 111 vs 119 - hence K > 8.
+          // (Four independent accumulator chains need 19 more registers: 1 wave per SIMD, 246 us.)
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+          for (int jj = 0; jj < 9; jj++) svec[tid * 9 + jj] = vec[jj];
+          __builtin_amdgcn_wave_barrier();  // a wave only reads the rows of its own 64 lanes
+          const int wbase = tid & ~63, ln = lane & 15, lk = lane >> 4;
+          for (int mt = 0; mt < K; mt += 16) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const bool am = mt + ln < K;
+#pragma unroll 4
+            for (int kk = 0; kk < 16; kk++) {
+              const int src = wbase + 4 * kk + lk;  // the Gaussian (lane of this wave) this operand element belongs to
+              const float av = am ? cf[src * KP + mt + ln] : 0.f;
+              const float bv = ln < 9 ? svec[src * 9 + ln] : 0.f;
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+            if (ln < 9) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const int m = mt + lk * 4 + r;  // D layout: row = (lane >> 4) * 4 + r, column = lane & 15
+                if (m < K) mine[m * 9 + ln] = acc[r];
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
         } else {
           for (int o = lane; o < nk; o += 64) mine[o] = 0.f;
         }
@@ -501,7 +532,7 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   const int K = dims->G > 0 ? dims->K : 0;
   const int KP = K | 1;
   size_t lds = sizeof(float) * ((((size_t)dims->S * K * 9 + 3) & ~(size_t)3) + 2 * (size_t)BLK * KP +
-                                8 * ((size_t)K * 9 + 13));
+                                8 * ((size_t)K * 9 + 13) + (size_t)BLK * 9);
   if (lds > 160 * 1024) {
     d4gs_set_error("project_bwd: LDS budget exceeded (S=%d K=%d)", dims->S, dims->K);
     return D4GS_EINVAL;
