@@ -393,11 +393,15 @@ for (N, W, H, sm) in ((30000, 320, 200, 2.5), (3000, 2320, 1040, 6.0)):   # 145 
 torch.save(outs, sys.argv[1])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for env_extra, name in (({}, "/tmp/d4gs_cnt_a.pt"), ({"D4GS_COUNT_IN_PROJECT": "1"}, "/tmp/d4gs_cnt_b.pt")):
+    # default: k_count_tiles + fused emission-offset scan (k_emit finishes it); then the same counting with the stand-alone
+    # scan kernels; then the in-kernel atomics
+    for env_extra, name in (({}, "/tmp/d4gs_cnt_a.pt"), ({"D4GS_NO_FUSED_SCAN": "1"}, "/tmp/d4gs_cnt_c.pt"),
+                            ({"D4GS_COUNT_IN_PROJECT": "1"}, "/tmp/d4gs_cnt_b.pt")):
         subprocess.check_call([sys.executable, "-c", code, name], env=dict(os.environ, **env_extra))
         res.append(torch.load(name))
-    for x, y in zip(*res):
-        assert torch.equal(x, y)
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert torch.equal(x, y)
 
 
 def _sweep_cases(n=14, seed=2026):
