@@ -44,7 +44,7 @@ class Raster(C.Structure):
 class RasterGrads(C.Structure):
     _fields_ = [(n, F) for n in ("v_render_colors", "v_render_alphas", "isect_grad", "isect_live", "v_means2d", "v_conics",
                                  "v_depths", "v_opac_act", "v_ctab", "stats_grad_norm_acc", "stats_vis_count",
-                                 "stats_max_radii")] + [("stats_batch_size", C.c_int32), ("stats_update_max_radii", C.c_int32)]
+                                 "stats_max_radii")] + [("stats_batch_size", C.c_int32), ("stats_update_max_radii", C.c_int32), ("row_mode", C.c_int32)]
 
 
 class Sizes(C.Structure):
@@ -72,15 +72,21 @@ class LeafGrads(C.Structure):
                                  "v_rots", "v_transls", "v_times", "v_RTs", "v_viewmat", "partials")]
 
 
+class Poses(C.Structure):
+    _fields_ = [("means", F), ("quats", F), ("transforms", F), ("g_major", C.c_int32)]
+
+
 RAW_PARAMS, RAW_COLORS, EXACT_CULL = 1, 2, 4
 DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
+ROWS_AUTO, ROWS_DENSE, ROWS_SPARSE = 0, 1, 2
 TILE = 16
+VERSION = 300  # D4GS_VERSION of include/d4gs.h
 GEOM_STRIDE = 8
 
 EXPORTS = (
     "d4gs_version", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
-    "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_control_stats", "d4gs_control_plan", "d4gs_gather_rows", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
+    "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_poses_fwd", "d4gs_poses_bwd", "d4gs_control_stats", "d4gs_control_plan", "d4gs_gather_rows", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
     "d4gs_pose_encode", "d4gs_pose_encode_bwd", "d4gs_move_model_fwd", "d4gs_move_model_bwd",
     "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_query_sizes", "d4gs_profile_enable", "d4gs_profile_collect",
 )
@@ -114,6 +120,8 @@ def lib() -> C.CDLL:
         L.d4gs_project_bwd.argtypes = [P(Dims), P(ProjIn), P(ProjOut), vp, vp, vp, vp, vp, P(LeafGrads), vp]
         L.d4gs_points_fwd.argtypes = [P(Dims), P(ProjIn), vp, vp]
         L.d4gs_points_bwd.argtypes = [P(Dims), P(ProjIn), vp, P(LeafGrads), vp]
+        L.d4gs_poses_fwd.argtypes = [P(Dims), P(ProjIn), P(Poses), vp]
+        L.d4gs_poses_bwd.argtypes = [P(Dims), P(ProjIn), P(Poses), P(LeafGrads), vp]
         L.d4gs_control_stats.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, vp]
         L.d4gs_control_plan.argtypes = [C.c_int32, vp, vp, vp, vp, vp]
         L.d4gs_gather_rows.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, C.c_int64, C.c_float, vp]
@@ -134,8 +142,8 @@ def lib() -> C.CDLL:
                                            C.c_float, vp, vp]
         L.d4gs_blend_fwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp]
         L.d4gs_blend_bwd.argtypes = [C.c_int32, C.c_int64, C.c_int32, P(C.c_int32), vp, vp, vp, vp, vp, vp, vp]
-        if L.d4gs_version() != 201:
-            raise RuntimeError(f"libd4gs.so version {L.d4gs_version()} != 201 (stale build?)")
+        if L.d4gs_version() != VERSION:
+            raise RuntimeError(f"libd4gs.so version {L.d4gs_version()} != {VERSION} (stale build?)")
         _lib = L
     return _lib
 

@@ -1,4 +1,5 @@
-"""Build libd4gs.so (HIP, gfx950 only) in-tree with hipcc.  `python -m deblur4dgs_amd.build [--force]`.
+"""Build libd4gs.so (HIP, gfx950 only) in-tree with hipcc.  `python -m deblur4dgs_amd.build [--force]` (also builds the
+tests' A/B library tests/libd4gs_variants.so).
 
 hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the build container; the resulting
 .so is git-ignored but travels to the GPU box with the repo snapshot.
@@ -14,7 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libd4gs.so")
+# A/B build for the tests only: the same sources with -DD4GS_VARIANTS, which adds the non-default composite kernels
+# (csrc/variants/*.inc, selected by D4GS_{FWD,BWD}_* environment variables).  Never loaded by the package itself.
+VARIANTS_LIB = os.path.join(HERE, "..", "tests", "libd4gs_variants.so")
+VARIANT_SOURCES = ("raster_fwd.hip", "raster_bwd.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+# per-file extras.  project_bwd: the SLP vectorizer turns the adjoint chain into v_pk_* math, which is not faster on gfx950 (4.5
+# cycles for two operations against 2.5 for one) and parks ~40 duplicated operands in VGPR pairs: 256 + 30 registers instead of 128
+FILE_FLAGS = {"project_bwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -26,13 +34,14 @@ def _stale(src: str, obj: str) -> bool:
         return True
     t = os.path.getmtime(obj)
     deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "d4gs.h")]
+    deps += [os.path.join(CSRC, "variants", f) for f in os.listdir(os.path.join(CSRC, "variants"))] if obj.endswith(".var.o") else []
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src: str, extra: list[str]) -> str:
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    if _stale(src, obj) or extra:
-        cmd = ["hipcc", *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+def _compile(src: str, extra: list[str], suffix: str = ".o") -> str:
+    obj = os.path.join(OBJ, src.replace(".hip", suffix))
+    if _stale(src, obj) or (extra and suffix == ".o"):
+        cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -58,5 +67,42 @@ def build(force: bool = False, extra: list[str] | None = None) -> str:
     return LIB
 
 
+def build_variants() -> str:
+    """tests/libd4gs_variants.so: raster_fwd / raster_bwd recompiled with -DD4GS_VARIANTS, every other object shared with
+    the product build (call build() first)."""
+    build()
+    objs = []
+    for s in _sources():
+        objs.append(_compile(s, ["-DD4GS_VARIANTS"], ".var.o") if s in VARIANT_SOURCES else os.path.join(OBJ, s.replace(".hip", ".o")))
+    if not os.path.exists(VARIANTS_LIB) or any(os.path.getmtime(o) > os.path.getmtime(VARIANTS_LIB) for o in objs):
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", VARIANTS_LIB, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return VARIANTS_LIB
+
+
+def build_ab(name: str, src: str, defines: list[str]) -> str:
+    """scripts/ablate/libd4gs_<name>.so: the product objects with `src` recompiled under extra -D flags (A/B timing of one
+    kernel on the GPU box: `D4GS_LIB_PATH=scripts/ablate/libd4gs_<name>.so python bench.py ...`)."""
+    build()
+    out_dir = os.path.join(HERE, "..", "scripts", "ablate")
+    os.makedirs(out_dir, exist_ok=True)
+    obj = os.path.join(out_dir, f"ab_{name}.o")
+    cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(src, []), *defines, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+    objs = [obj if s == src else os.path.join(OBJ, s.replace(".hip", ".o")) for s in _sources()]
+    lib = os.path.join(out_dir, f"libd4gs_{name}.so")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if len(sys.argv) > 3 and sys.argv[1] == "--ab":  # python -m deblur4dgs_amd.build --ab <name> <src.hip> [-DX=1 ...]
+        print(build_ab(sys.argv[2], sys.argv[3], sys.argv[4:]))
+    else:
+        print(build(force="--force" in sys.argv))
+        print(build_variants())

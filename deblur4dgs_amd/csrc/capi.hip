@@ -14,8 +14,8 @@ int d4gs_raster_bwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect 
                          const D4gsRasterGrads *, hipStream_t);
 int d4gs_project_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, const float *, const float *,
                           const float *, const float *, const float *, const D4gsLeafGrads *, hipStream_t);
-int d4gs_points_fwd_impl(const D4gsDims *, const D4gsProjIn *, float *, hipStream_t);
-int d4gs_points_bwd_impl(const D4gsDims *, const D4gsProjIn *, const float *, const D4gsLeafGrads *, hipStream_t);
+int d4gs_poses_fwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsPoses *, hipStream_t);
+int d4gs_poses_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsPoses *, const D4gsLeafGrads *, hipStream_t);
 int d4gs_control_stats_impl(int32_t, int32_t, const float *, const int32_t *, int32_t, int32_t, int32_t, float *,
                             int64_t *, float *, int32_t, hipStream_t);
 int d4gs_control_plan_impl(int32_t, const uint8_t *, const uint8_t *, int32_t *, int32_t *, hipStream_t);
@@ -260,36 +260,61 @@ int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
                                (hipStream_t)stream);
 }
 
-static int check_points(const D4gsDims *d, const D4gsProjIn *in) {
-  if (!d || !in || d->N <= 0 || d->S <= 0 || d->G < 0 || d->G > d->N || !in->means || !in->viewmat || !in->Kmat ||
+static int check_poses(const char *who, const D4gsDims *d, const D4gsProjIn *in, int need_quats) {
+  if (!d || !in || d->N <= 0 || d->S <= 0 || d->G < 0 || d->G > d->N || !in->means || (in->viewmat && !in->Kmat) ||
+      (need_quats && !in->quats) ||
       (d->G > 0 && (d->K <= 0 || d->K > D4GS_MAX_K || d->T <= 0 || !in->motion_coefs || !in->rots || !in->transls ||
                     !in->times))) {
-    d4gs_set_error("d4gs_points_*: bad dims or NULL required input");
+    d4gs_set_error("%s: bad dims or NULL required input", who);
     return D4GS_EINVAL;
   }
   return D4GS_OK;
 }
 
-int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points, void *stream) {
-  int rc = check_points(dims, in);
+int d4gs_poses_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *out, void *stream) {
+  if (!out || (!out->means && !out->quats && !out->transforms)) {
+    d4gs_set_error("d4gs_poses_fwd: no output requested");
+    return D4GS_EINVAL;
+  }
+  int rc = check_poses("d4gs_poses_fwd", dims, in, out->quats != NULL);
   if (rc) return rc;
+  return d4gs_poses_fwd_impl(dims, in, out, (hipStream_t)stream);
+}
+
+int d4gs_poses_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *v_out, const D4gsLeafGrads *grads,
+                   void *stream) {
+  if (!v_out) {
+    d4gs_set_error("d4gs_poses_bwd: NULL gradient struct");
+    return D4GS_EINVAL;
+  }
+  int rc = check_poses("d4gs_poses_bwd", dims, in, v_out->quats != NULL);
+  if (rc) return rc;
+  if (!grads || !grads->v_means || !grads->partials || (v_out->quats && !grads->v_quats) ||
+      (dims->G > 0 && (!grads->v_motion_coefs || !grads->v_rots || !grads->v_transls))) {
+    d4gs_set_error("d4gs_poses_bwd: NULL gradient buffer");
+    return D4GS_EINVAL;
+  }
+  return d4gs_poses_bwd_impl(dims, in, v_out, grads, (hipStream_t)stream);
+}
+
+/* a11 track channels: the means half of the pose API in the target cameras, time-major */
+int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points, void *stream) {
   if (!points) {
     d4gs_set_error("d4gs_points_fwd: NULL output");
     return D4GS_EINVAL;
   }
-  return d4gs_points_fwd_impl(dims, in, points, (hipStream_t)stream);
+  D4gsPoses o = {points, NULL, NULL, 0};
+  return d4gs_poses_fwd(dims, in, &o, stream);
 }
 
 int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points, const D4gsLeafGrads *grads,
                     void *stream) {
-  int rc = check_points(dims, in);
-  if (rc) return rc;
-  if (!v_points || !grads || !grads->v_means || !grads->partials ||
-      (dims->G > 0 && (!grads->v_motion_coefs || !grads->v_rots || !grads->v_transls))) {
-    d4gs_set_error("d4gs_points_bwd: NULL gradient buffer");
+  if (!v_points) {
+    d4gs_set_error("d4gs_points_bwd: NULL gradient");
     return D4GS_EINVAL;
   }
-  return d4gs_points_bwd_impl(dims, in, v_points, grads, (hipStream_t)stream);
+  D4gsPoses v = {(float *)v_points, NULL, NULL, 0};
+  return d4gs_poses_bwd(dims, in, &v, grads, stream);
 }
 
 int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad, const int32_t *radii, int32_t width, int32_t height,

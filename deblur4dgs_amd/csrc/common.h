@@ -73,6 +73,110 @@ __device__ __forceinline__ void gram_schmidt(const float *r6, GS6 &o) {
   o.z[2] = o.x[0] * o.y[1] - o.x[1] * o.y[0];
 }
 
+// ---- pose compose on quaternions (flow3d/scene_model.py:94-102; roma 1.5.0 conventions, XYZW storage there) --------
+// rotmat_to_unitquat: 4-way branch on argmax(R00, R11, R22, trace) (first maximum wins), candidate c (x, y, z, w),
+// then c / |c|.  I = 0..2: the diagonal branches, I = 3: the trace branch.
+__device__ __forceinline__ int rq_choice(const float *R) {
+  const float tr = R[0] + R[4] + R[8];
+  int ch = 0;
+  float best = R[0];
+  if (R[4] > best) best = R[4], ch = 1;
+  if (R[8] > best) best = R[8], ch = 2;
+  if (tr > best) ch = 3;
+  return ch;
+}
+template <int I>
+__device__ __forceinline__ void rq_cand(const float *R, float *c) {
+  const float tr = R[0] + R[4] + R[8];
+  if constexpr (I == 3) {
+    c[0] = R[7] - R[5], c[1] = R[2] - R[6], c[2] = R[3] - R[1], c[3] = 1.f + tr;
+  } else {
+    constexpr int J = (I + 1) % 3, Kk = (I + 2) % 3;
+    c[I] = 1.f - tr + 2.f * R[I * 3 + I];
+    c[J] = R[J * 3 + I] + R[I * 3 + J];
+    c[Kk] = R[Kk * 3 + I] + R[I * 3 + Kk];
+    c[3] = R[Kk * 3 + J] - R[J * 3 + Kk];
+  }
+}
+template <int I>
+__device__ __forceinline__ void rq_cand_adj(const float *vc, float *vR) {  // vR += (d c / d R)^T vc
+  if constexpr (I == 3) {
+    vR[7] += vc[0], vR[5] -= vc[0], vR[2] += vc[1], vR[6] -= vc[1], vR[3] += vc[2], vR[1] -= vc[2];
+    vR[0] += vc[3], vR[4] += vc[3], vR[8] += vc[3];
+  } else {
+    constexpr int J = (I + 1) % 3, Kk = (I + 2) % 3;
+    vR[I * 3 + I] += vc[I], vR[J * 3 + J] -= vc[I], vR[Kk * 3 + Kk] -= vc[I];
+    vR[J * 3 + I] += vc[J], vR[I * 3 + J] += vc[J];
+    vR[Kk * 3 + I] += vc[Kk], vR[I * 3 + Kk] += vc[Kk];
+    vR[Kk * 3 + J] += vc[3], vR[J * 3 + Kk] -= vc[3];
+  }
+}
+__device__ __forceinline__ void rq_cand_dyn(int ch, const float *R, float *c) {
+  if (ch == 0) rq_cand<0>(R, c);
+  else if (ch == 1) rq_cand<1>(R, c);
+  else if (ch == 2) rq_cand<2>(R, c);
+  else rq_cand<3>(R, c);
+}
+__device__ __forceinline__ void rq_cand_adj_dyn(int ch, const float *vc, float *vR) {
+  if (ch == 0) rq_cand_adj<0>(vc, vR);
+  else if (ch == 1) rq_cand_adj<1>(vc, vR);
+  else if (ch == 2) rq_cand_adj<2>(vc, vR);
+  else rq_cand_adj<3>(vc, vR);
+}
+// Hamilton product r = p (x) q, all (w, x, y, z)
+__device__ __forceinline__ void quat_mul(const float *p, const float *q, float *r) {
+  r[0] = p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3];
+  r[1] = p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2];
+  r[2] = p[0] * q[2] - p[1] * q[3] + p[2] * q[0] + p[3] * q[1];
+  r[3] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+}
+__device__ __forceinline__ void quat_mul_adj(const float *p, const float *q, const float *vr, float *vp, float *vq) {
+  vp[0] = vr[0] * q[0] + vr[1] * q[1] + vr[2] * q[2] + vr[3] * q[3];
+  vp[1] = -vr[0] * q[1] + vr[1] * q[0] - vr[2] * q[3] + vr[3] * q[2];
+  vp[2] = -vr[0] * q[2] + vr[1] * q[3] + vr[2] * q[0] - vr[3] * q[1];
+  vp[3] = -vr[0] * q[3] - vr[1] * q[2] + vr[2] * q[1] + vr[3] * q[0];
+  vq[0] = vr[0] * p[0] + vr[1] * p[1] + vr[2] * p[2] + vr[3] * p[3];
+  vq[1] = -vr[0] * p[1] + vr[1] * p[0] + vr[2] * p[3] - vr[3] * p[2];
+  vq[2] = -vr[0] * p[2] - vr[1] * p[3] + vr[2] * p[0] + vr[3] * p[1];
+  vq[3] = -vr[0] * p[3] + vr[1] * p[2] - vr[2] * p[1] + vr[3] * p[0];
+}
+// compose: q_out = normalize( rotmat_to_unitquat(Rd) (x) qh ), everything (w, x, y, z); qh is the unit Gaussian quaternion.
+// Keeps what the adjoint needs.
+struct PoseQ {
+  int ch;
+  float p[4];      // unit quaternion of Rd (w, x, y, z)
+  float inv_nc;    // 1 / |candidate|
+  float out[4];    // the result
+  float inv_nr;    // 1 / max(|product|, 1e-12)
+};
+__device__ __forceinline__ void pose_quat(const float *Rd, const float *qh, PoseQ &o) {
+  float c[4];
+  o.ch = rq_choice(Rd);
+  rq_cand_dyn(o.ch, Rd, c);
+  o.inv_nc = 1.f / sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]);
+  o.p[0] = c[3] * o.inv_nc, o.p[1] = c[0] * o.inv_nc, o.p[2] = c[1] * o.inv_nc, o.p[3] = c[2] * o.inv_nc;
+  float r[4];
+  quat_mul(o.p, qh, r);
+  o.inv_nr = 1.f / fmaxf(sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]), 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 4; i++) o.out[i] = r[i] * o.inv_nr;
+}
+// adjoint: v_out (w,x,y,z) -> vRd += ..., v_qh += ...
+__device__ __forceinline__ void pose_quat_adj(const PoseQ &o, const float *qh, const float *v_out, float *vRd, float *v_qh) {
+  const float dt = v_out[0] * o.out[0] + v_out[1] * o.out[1] + v_out[2] * o.out[2] + v_out[3] * o.out[3];
+  float vr[4], vp[4], vq[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) vr[i] = (v_out[i] - dt * o.out[i]) * o.inv_nr;
+  quat_mul_adj(o.p, qh, vr, vp, vq);
+#pragma unroll
+  for (int i = 0; i < 4; i++) v_qh[i] += vq[i];
+  const float dp = vp[0] * o.p[0] + vp[1] * o.p[1] + vp[2] * o.p[2] + vp[3] * o.p[3];
+  float vc[4];  // candidate order (x, y, z, w)
+  vc[0] = (vp[1] - dp * o.p[1]) * o.inv_nc, vc[1] = (vp[2] - dp * o.p[2]) * o.inv_nc;
+  vc[2] = (vp[3] - dp * o.p[3]) * o.inv_nc, vc[3] = (vp[0] - dp * o.p[0]) * o.inv_nc;
+  rq_cand_adj_dyn(o.ch, vc, vRd);
+}
+
 // gsplat isect_tiles rectangle: tile_min inclusive, tile_max exclusive (float32 arithmetic as upstream)
 __device__ __forceinline__ void tile_rect(float mx, float my, int radius, int tw, int th, int &x0, int &y0, int &x1,
                                           int &y1) {

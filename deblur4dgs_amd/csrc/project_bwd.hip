@@ -1,20 +1,30 @@
 // project_bwd.hip -- adjoint of project_fwd.hip: projection, camera delta, motion-basis deformation and the
-// activations, for ALL S sub-samples, reduced to leaf gradients.
+// activations, for ALL S sub-samples, reduced to leaf gradients; and (MODE_POSES) the adjoint of d4gs_poses_fwd.
 //
 // Replaces gsplat fully_fused_projection_bwd and the torch autograd of flow3d/scene_model.py:67-120,352-353,
 // flow3d/params.py:39-43,142-180, flow3d/transforms.py:41-53 (reference backward: flow3d/trainer.py:231).
 //
-// One lane per Gaussian, looping over the sub-samples: per-Gaussian leaf gradients (means, quats, scales,
-// opacity, colours, motion coefficients) are accumulated over S in registers / LDS in a FIXED order and written
-// once - no atomics.  The small SHARED gradients (time-blended bases S*K*9, camera deltas S*12, viewmat 12) are
-// reduced per block through LDS column sums, written as per-block partials, summed over blocks by a second kernel
-// in a fixed order, and finally scattered to rots / transls / times by k_finish.  Every sum is deterministic.
+// Work decomposition (round 3): a 256-lane block owns 64 Gaussians; its 4 waves are 4 sub-sample SLOTS.  Lane l of
+// wave w evaluates the adjoint chain of instance (Gaussian g0 + l, sub-sample s) for s = w, w + 4, w + 8, ...  So
+//   * the sub-sample is WAVE-UNIFORM: its time-blended bases are one small LDS slab per wave (any S; round 2 kept all
+//     S*K*9 of them resident), its camera delta is scalar loads, per-instance loads are fully coalesced;
+//   * a shared gradient of sub-sample s (bases, camera delta) is the reduction of ONE wave: the wave ladder writes the
+//     block partial directly - no cross-wave sum, no block barrier inside the sub-sample loop;
+//   * per-Gaussian leaf gradients are accumulated over a slot's sub-samples in registers (fixed order), the 4 slots are
+//     then added through LDS in fixed order ((0+1)+(2+3)) and written once - no atomics, bit-reproducible.
+// (Round 2: one lane per Gaussian looping over S with 27 accumulators at 253 VGPRs, 2 waves / SIMD, 4 688 waves for
+// 2 048 wave slots on cfg2.)  Block partials of the shared gradients are summed over blocks by k_reduce_partials in a
+// fixed order and scattered to rots / transls / times by k_finish.
 #include "common.h"
 
 namespace {
 
-constexpr int BLK = D4GS_PROJ_BLOCK;
-constexpr int NV = 21;  // per-thread per-s vector: v9 (transl 3 + r6 6) + camera-delta adjoint 12; odd stride
+constexpr int BLK = 256;
+constexpr int GPB = 64;   // Gaussians per block = lanes of a wave
+constexpr int SLOTS = 4;  // sub-sample slots = waves of a block
+constexpr int NACC = 23;  // per-lane accumulators, kept in LDS (ds_add_f32 by their owner lane only): v_mu 3, v_q 4, v_sc 3,
+                          // v_view 12 (+1: odd stride)
+enum { MODE_RENDER = 0, MODE_POSES = 1 };
 
 struct BwdArgs {
   D4gsDims d;
@@ -26,59 +36,79 @@ struct BwdArgs {
   const float *v_means2d, *v_conics, *v_depths, *v_opac_act, *v_ctab;
   D4gsLeafGrads g;
   int n_shared;  // S*(9K+12)+12
-  const float *v_points;  // non-null: "points only" mode - adjoint of d4gs_points_fwd ([S,N,3] camera-space means)
+  // MODE_POSES (adjoint of d4gs_poses_fwd / d4gs_points_fwd); any of the three may be NULL = zero gradient
+  const float *v_points;      // [S,N,3] | [N,S,3]
+  const float *v_quats_out;   // [S,N,4] | [N,S,4]
+  const float *v_transforms;  // [S,G,3,4] | [G,S,3,4]
+  int g_major;                // 1: the Gaussian-major layouts (the reference's (G,B,...) tensors)
+  int persist;                // 1: a fixed grid of blocks walks the 64-Gaussian groups and keeps its shared-gradient sums in LDS
 };
 
-__device__ __forceinline__ void preblend_bases_b(const BwdArgs &a, float *Bs) {
-  const int K = a.d.K, T = a.d.T;
-  for (int idx = threadIdx.x; idx < a.d.S * K * 9; idx += blockDim.x) {
-    int s = idx / (K * 9), r = idx - s * K * 9, k = r / 9, j = r - k * 9;
-    float t = a.in.times[s];
-    float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));
-    float cf = fminf(fmaxf(ceilf(t), 0.f), (float)(T - 1));
-    float w = t - ff;
-    int f = (int)ff, c = (int)cf;
-    float vf, vc;
-    if (j < 3) {
-      vf = a.in.transls[(k * T + f) * 3 + j];
-      vc = a.in.transls[(k * T + c) * 3 + j];
-    } else {
-      vf = a.in.rots[(k * T + f) * 6 + j - 3];
-      vc = a.in.rots[(k * T + c) * 6 + j - 3];
-    }
-    Bs[idx] = (1.f - w) * vf + w * vc;
-  }
+#ifndef PB_NO_SB
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SB()
+#endif
+// accumulate into the lane's private LDS row: plain read-modify-write (ds_add_f32, 22 per pass, measured 2.6x slower for the
+// whole kernel: 306 vs 117 us on cfg2 - LDS float atomics run at a fraction of the plain DS rate on gfx950)
+#define ACC(slot_, val_) ac[slot_] += (val_)
+
+// v_q += (d R(q) / d q)^T vR for a unit quaternion q = (w, x, y, z)
+__device__ __forceinline__ void rotmat_adj_to_quat(const float *q, const float *vR, float *v_q) {
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  v_q[0] += 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+  v_q[1] += 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[3] + vR[1]) + z * (vR[6] + vR[2]) + w * (vR[7] - vR[5]));
+  v_q[2] += 2.f * (x * (vR[3] + vR[1]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[7] + vR[5]) + w * (vR[2] - vR[6]));
+  v_q[3] += 2.f * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
 }
 
-__global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
+template <int MODE, bool MFMA /* K > 8: basis-gradient column sums on the matrix pipe */>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ? 3 : 4))) k_project_bwd(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const D4gsDims &d = a.d;
-  const int N = d.N, G = d.G, K = d.K, S = d.S;
-  const int KP = K | 1;
-  const int nBs = (S * K * 9 + 3) & ~3;
-  float *Bs = smem;                  // [S][K][9]
-  float *cf = Bs + nBs;              // [BLK][KP]   softmaxed coefficients
-  float *vcf = cf + BLK * KP;        // [BLK][KP]   their gradients, summed over s
-  float *psum = vcf + BLK * KP;       // [2][4][9K+13]  per-wave segment sums (+ dump slot), double-buffered over s
-  float *svec = psum + 8 * (9 * K + 13);  // [BLK][9]  this sub-sample's (v_transl 3, v_r6 6) of every lane: MFMA B operand
-  const int tid = threadIdx.x;
-  const int g = blockIdx.x * BLK + tid;
-  const Cam cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
+  const int N = d.N, G = d.G, S = d.S;
   const bool dyn = G > 0;
-  const bool dyn_block = (blockIdx.x * BLK) < G;
-  if (dyn_block) preblend_bases_b(a, Bs);
+  const int K = dyn ? d.K : 0;
+  const int KP = K | 1;
+  const int nk = K * 9, nk4 = (nk + 3) & ~3, nop = nk + 13;
+  const bool shared = dyn || a.in.RTs;
+  const int no = nk + 12;
+  float *cf = smem;                   // [GPB][KP]    softmaxed coefficients of the block's Gaussians
+  float *vcf = cf + GPB * KP;         // [BLK][KP]    their gradients, per slot, summed over the slot's sub-samples
+  float *bsl = vcf + BLK * KP;        // [SLOTS][2][nk4] time-blended bases of the sub-sample each wave is working on / will work on next
+  float *red = bsl + 2 * SLOTS * nk4; // [SLOTS][nop] per-wave reduction slab (+ dump slot)
+  float *accs = red + SLOTS * nop;    // [BLK][NACC]  per-lane leaf accumulators (cross-slot sum at the end)
+  float *svec = accs + BLK * NACC;    // [BLK][9]     K > 8 only: (v_transl 3, v_r6 6) of every lane, MFMA B operand
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool raw = d.flags & D4GS_RAW_PARAMS;
+  const bool has_cam = MODE == MODE_RENDER || a.in.viewmat != nullptr;
+  Cam cam;
+  if (has_cam) cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
+  // Persistent blocks: block b walks the groups b, b + gridDim.x, ... and adds every group's shared-gradient sums into
+  // wacc (each (sub-sample, element) is owned by one wave, the groups come in a fixed order -> deterministic); ONE partial
+  // vector per block leaves the kernel instead of one per group (cfg5: 120 MB of partials written and read back).
+  float *wacc = svec + (MFMA ? BLK * 9 : 0);  // [n_shared], persist only
+  if (a.persist) {
+    for (int o = tid; o < a.n_shared; o += BLK) wacc[o] = 0.f;
+  }
+  const int ngroups = (N + GPB - 1) / GPB;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  const int g = grp * GPB + lane;
+  const bool dyn_block = (grp * GPB) < G;
   const bool active = g < N;
   const bool isdyn = active && g < G;
-  const bool raw = d.flags & D4GS_RAW_PARAMS;
-  const bool pts = a.v_points != nullptr;
 
-  float mu[3] = {0, 0, 0}, Rq[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, sc[3] = {1, 1, 1}, qh[4] = {1, 0, 0, 0}, inv_qn = 1.f;
+  float mu[3] = {0, 0, 0}, sc[3] = {1, 1, 1}, qh[4] = {1, 0, 0, 0}, inv_qn = 1.f;
   if (active) mu[0] = a.in.means[g * 3], mu[1] = a.in.means[g * 3 + 1], mu[2] = a.in.means[g * 3 + 2];
-  if (active && !pts) {
+  const bool need_q = MODE == MODE_RENDER || a.v_quats_out != nullptr;
+  if (active && need_q) {
     const float4 q = *reinterpret_cast<const float4 *>(a.in.quats + (size_t)g * 4);
     inv_qn = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
     qh[0] = q.x * inv_qn, qh[1] = q.y * inv_qn, qh[2] = q.z * inv_qn, qh[3] = q.w * inv_qn;
-    quat_to_rotmat(qh[0], qh[1], qh[2], qh[3], Rq);
+  }
+  if (MODE == MODE_RENDER && active) {
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       float v = a.in.scales[g * 3 + j];
@@ -86,148 +116,242 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
     }
   }
   if (dyn_block) {
-    for (int k = 0; k < K; k++) cf[tid * KP + k] = 0.f, vcf[tid * KP + k] = 0.f;
-    if (isdyn) {
-      const float *mc = a.in.motion_coefs + (size_t)g * K;
-      float m = -INFINITY;
-      for (int k = 0; k < K; k++) m = fmaxf(m, mc[k]);
-      float sum = 0.f;
-      for (int k = 0; k < K; k++) {
-        float e = expf(mc[k] - m);
-        cf[tid * KP + k] = e;
-        sum += e;
+    for (int k = 0; k < K; k++) vcf[tid * KP + k] = 0.f;
+    if (slot == 0) {  // softmax(motion_coefs) params.py:43, once per Gaussian
+      for (int k = 0; k < K; k++) cf[lane * KP + k] = 0.f;
+      if (MODE == MODE_POSES && isdyn && !raw) {  // activated coefficients, used as given
+        for (int k = 0; k < K; k++) cf[lane * KP + k] = a.in.motion_coefs[(size_t)g * K + k];
+      } else if (isdyn) {
+        const float *mc = a.in.motion_coefs + (size_t)g * K;
+        float m = -INFINITY;
+        for (int k = 0; k < K; k++) m = fmaxf(m, mc[k]);
+        float sum = 0.f;
+        for (int k = 0; k < K; k++) {
+          float e = expf(mc[k] - m);
+          cf[lane * KP + k] = e;
+          sum += e;
+        }
+        float is = 1.f / sum;
+        for (int k = 0; k < K; k++) cf[lane * KP + k] *= is;
       }
-      float is = 1.f / sum;
-      for (int k = 0; k < K; k++) cf[tid * KP + k] *= is;
     }
   }
   __syncthreads();
 
-  float v_mu[3] = {0, 0, 0}, v_Rq[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v_sc[3] = {0, 0, 0};
-  float v_view[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // dL/dRcw (9, row-major) then dL/dt (3)
-  float *part = a.g.partials + (size_t)blockIdx.x * a.n_shared;
-
-  for (int s = 0; s < S; s++) {
-    float vec[NV];
+  // accumulators over the slot's sub-samples live in LDS, one private row per lane (22 registers less across the chain;
+  // a row is only ever touched by its own lane, in program order -> deterministic)
+  float *ac = accs + tid * NACC;  // [0:3] v_mu, [3:7] v_q, [7:10] sc * v_sc, [10:22] dL/dRcw (9, row-major) then dL/dt (3)
 #pragma unroll
-    for (int r = 0; r < NV; r++) vec[r] = 0.f;
-    const size_t i = (size_t)s * N + (active ? g : 0);
-    if (active && (pts || a.radii[i] > 0)) {
-      // ---- recompute the forward ----
-      float mw0[3], Rm[9], Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, v9[9];
-      GS6 gs;
+  for (int c = 0; c < NACC - 1; c++) ac[c] = 0.f;
+  float *part = a.persist ? wacc : a.g.partials + (size_t)grp * a.n_shared;
+  float *mine = red + slot * nop;
+
+  // Time-blended bases of sub-sample s (params.py:152-177; w uses the clamped floor): element idx = lane + 64 m of the
+  // wave's [K][9] slab.  The loads for the NEXT sub-sample of this slot are issued at the top of a pass and the slab is
+  // written at its end (two slabs per wave), so their latency hides behind the adjoint chain.
+  constexpr int NBV = MFMA ? (D4GS_MAX_K * 9 + 63) / 64 : 2;  // K <= 8 without the matrix pipe: 72 elements
+  float bvf[NBV], bvc[NBV], bw = 0.f;
+  auto bases_load = [&](int s_) {
+    const int T = d.T;
+    const float t = a.in.times[s_];
+    const float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));
+    const float cfl = fminf(fmaxf(ceilf(t), 0.f), (float)(T - 1));
+    bw = t - ff;
+    const int f = (int)ff, c = (int)cfl;
+#pragma unroll
+    for (int m = 0; m < NBV; m++) {
+      const int idx = lane + 64 * m;
+      bvf[m] = bvc[m] = 0.f;
+      if (idx < nk) {
+        const int k = idx / 9, j = idx - k * 9;
+        if (j < 3) {
+          bvf[m] = a.in.transls[(k * T + f) * 3 + j];
+          bvc[m] = a.in.transls[(k * T + c) * 3 + j];
+        } else {
+          bvf[m] = a.in.rots[(k * T + f) * 6 + j - 3];
+          bvc[m] = a.in.rots[(k * T + c) * 6 + j - 3];
+        }
+      }
+    }
+  };
+  auto bases_store = [&](float *dst) {
+#pragma unroll
+    for (int m = 0; m < NBV; m++) {
+      const int idx = lane + 64 * m;
+      if (idx < nk) dst[idx] = (1.f - bw) * bvf[m] + bw * bvc[m];
+    }
+  };
+  int cur = 0;
+  if (dyn_block && slot < S) {
+    bases_load(slot);
+    bases_store(bsl + (slot * 2) * nk4);
+  }
+
+  for (int s = slot; s < S; s += SLOTS, cur ^= 1) {  // wave-uniform
+    const float *B = bsl + (slot * 2 + cur) * nk4;
+    const bool more = dyn_block && s + SLOTS < S;
+    __builtin_amdgcn_wave_barrier();
+    if (more) bases_load(s + SLOTS);
+    float vec[21];  // v9 adjoint (transl 3 + r6 6) + camera-delta adjoint 12
+#pragma unroll
+    for (int r = 0; r < 21; r++) vec[r] = 0.f;
+    const unsigned i = (MODE == MODE_POSES && a.g_major) ? (unsigned)(active ? g : 0) * S + s : (unsigned)s * N + (active ? g : 0);  // < 2^28
+    // every per-instance input of the pass is requested here, up front: the deformation forward (phase 1) needs none of
+    // them and runs while they are in flight
+    int radius = 0;
+    float in_con[3] = {0, 0, 0}, in_vcon[3] = {0, 0, 0}, in_vm2[2] = {0, 0}, in_vdep = 0.f;
+    if (MODE == MODE_RENDER && active) {
+      radius = a.radii[i];
+#pragma unroll
+      for (int c = 0; c < 3; c++) in_con[c] = a.conics[i * 3 + c], in_vcon[c] = a.v_conics[i * 3 + c];
+      in_vm2[0] = a.v_means2d[i * 2], in_vm2[1] = a.v_means2d[i * 2 + 1];
+      in_vdep = a.v_depths[i];
+    }
+    if (active) {
+      // The chain is written phase by phase with scheduling fences (SB) between the phases: left alone, the scheduler
+      // interleaves the ~1500 independent multiply-adds of the whole chain for ILP and needs > 256 VGPRs (round 2:
+      // 253 VGPRs, 2 waves / SIMD); fenced, the live set at any point is what the mathematics needs.
+      // ---- phase 1: deformation forward ----
+      float mw0[3], Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bb[3] = {0, 0, 0};
+      float gs_inv_na = 1.f, gs_inv_nb = 1.f, gs_d = 0.f;
       if (isdyn) {
+        float v9[9];
 #pragma unroll
         for (int j = 0; j < 9; j++) v9[j] = 0.f;
-        const float *B = Bs + s * K * 9;
         for (int k = 0; k < K; k++) {
-          float c = cf[tid * KP + k];
+          float c = cf[lane * KP + k];
 #pragma unroll
           for (int j = 0; j < 9; j++) v9[j] += c * B[k * 9 + j];
         }
+        GS6 gs;
         gram_schmidt(v9 + 3, gs);
         Rd[0] = gs.x[0], Rd[1] = gs.y[0], Rd[2] = gs.z[0];
         Rd[3] = gs.x[1], Rd[4] = gs.y[1], Rd[5] = gs.z[1];
         Rd[6] = gs.x[2], Rd[7] = gs.y[2], Rd[8] = gs.z[2];
+        gs_inv_na = gs.inv_na, gs_inv_nb = gs.inv_nb, gs_d = gs.d;
+        bb[0] = v9[6], bb[1] = v9[7], bb[2] = v9[8];
 #pragma unroll
         for (int r = 0; r < 3; r++) mw0[r] = Rd[r * 3] * mu[0] + Rd[r * 3 + 1] * mu[1] + Rd[r * 3 + 2] * mu[2] + v9[r];
-        mat3_mul(Rd, Rq, Rm);
       } else {
 #pragma unroll
         for (int r = 0; r < 3; r++) mw0[r] = mu[r];
-#pragma unroll
-        for (int r = 0; r < 9; r++) Rm[r] = Rq[r];
       }
-      float mw[3] = {mw0[0], mw0[1], mw0[2]};
-      float RT[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-      if (a.in.RTs) {
+      SB();
+      if (MODE == MODE_POSES || radius > 0) {
+      float v_mw[3] = {0, 0, 0}, vRm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (MODE == MODE_POSES) {
+        float v_pc[3] = {0, 0, 0};
+        if (a.v_points) {
 #pragma unroll
-        for (int r = 0; r < 12; r++) RT[r] = a.in.RTs[s * 12 + r];
-#pragma unroll
-        for (int r = 0; r < 3; r++) mw[r] = RT[r * 4] * mw0[0] + RT[r * 4 + 1] * mw0[1] + RT[r * 4 + 2] * mw0[2] + RT[r * 4 + 3];
-      }
-      float v_pc[3], vRm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (pts) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) v_pc[r] = a.v_points[i * 3 + r];
-      } else {
-        ProjOut p;
-        D4gsDims dd = d;
-        dd.near_plane = -INFINITY, dd.far_plane = INFINITY;  // the visibility decision is the saved radius
-        project_instance(cam, mw, Rm, sc, dd, p);
-        // ---- adjoint of conic = inverse(cov2d_blur) ----
-        const float A = a.conics[i * 3], Bc = a.conics[i * 3 + 1], C = a.conics[i * 3 + 2];
-        const float vA = a.v_conics[i * 3], vB = 0.5f * a.v_conics[i * 3 + 1], vC = a.v_conics[i * 3 + 2];
-        const float t00 = A * vA + Bc * vB, t01 = A * vB + Bc * vC, t10 = Bc * vA + C * vB, t11 = Bc * vB + C * vC;
-        const float w00 = -(t00 * A + t01 * Bc), w01 = -(t00 * Bc + t01 * C), w11 = -(t10 * Bc + t11 * C);
-        // ---- cov2d = J covc J^T ----
-        const float rz = p.rz, rz2 = rz * rz, rz3 = rz2 * rz;
-        const float J00 = cam.fx * rz, J11 = cam.fy * rz, J02 = p.J02, J12 = p.J12;
-        const float cxx = p.covc[0], cxy = p.covc[1], cxz = p.covc[2], cyy = p.covc[3], cyz = p.covc[4], czz = p.covc[5];
-        // JS = J covc (2x3)
-        const float js00 = J00 * cxx + J02 * cxz, js01 = J00 * cxy + J02 * cyz, js02 = J00 * cxz + J02 * czz;
-        const float js10 = J11 * cxy + J12 * cxz, js11 = J11 * cyy + J12 * cyz, js12 = J11 * cyz + J12 * czz;
-        // v_J = 2 * w * JS  (only the structurally non-zero entries)
-        const float vJ00 = 2.f * (w00 * js00 + w01 * js10);
-        const float vJ02 = 2.f * (w00 * js02 + w01 * js12);
-        const float vJ11 = 2.f * (w01 * js01 + w11 * js11);
-        const float vJ12 = 2.f * (w01 * js02 + w11 * js12);
-        // v_covc = J^T w J (symmetric 3x3)
-        const float a0 = w00 * J00, a1 = w01 * J11, a2 = w00 * J02 + w01 * J12;  // row 0 of (w J)
-        const float b0 = w01 * J00, b1 = w11 * J11, b2 = w01 * J02 + w11 * J12;  // row 1 of (w J)
-        float vS[9];
-        vS[0] = J00 * a0, vS[1] = J00 * a1, vS[2] = J00 * a2;
-        vS[3] = J11 * b0, vS[4] = J11 * b1, vS[5] = J11 * b2;
-        vS[6] = J02 * a0 + J12 * b0, vS[7] = J02 * a1 + J12 * b1, vS[8] = J02 * a2 + J12 * b2;
-        // ---- camera-space mean ----
-        const float vm0 = a.v_means2d[i * 2], vm1 = a.v_means2d[i * 2 + 1];
-        const float x = p.pc[0], y = p.pc[1], z = p.pc[2];
-        const float tx = -J02 / (cam.fx * rz2), ty = -J12 / (cam.fy * rz2);
-        v_pc[0] = cam.fx * rz * vm0;
-        v_pc[1] = cam.fy * rz * vm1;
-        v_pc[2] = -(cam.fx * x * vm0 + cam.fy * y * vm1) * rz2 + a.v_depths[i];
-        if (p.in_x) v_pc[0] += -cam.fx * rz2 * vJ02; else v_pc[2] += -cam.fx * rz3 * vJ02 * tx;
-        if (p.in_y) v_pc[1] += -cam.fy * rz2 * vJ12; else v_pc[2] += -cam.fy * rz3 * vJ12 * ty;
-        v_pc[2] += -cam.fx * rz2 * vJ00 - cam.fy * rz2 * vJ11 + 2.f * cam.fx * tx * rz3 * vJ02 + 2.f * cam.fy * ty * rz3 * vJ12;
-        (void)z;
-        // ---- covc = M M^T, M = (Rcw Rm) diag(sc) ----
-        float vM[9];
-        {
-          float sym[9];
-  #pragma unroll
-          for (int r = 0; r < 3; r++)
-  #pragma unroll
-            for (int c = 0; c < 3; c++) sym[r * 3 + c] = vS[r * 3 + c] + vS[c * 3 + r];
-          mat3_mul(sym, p.M, vM);
+          for (int r = 0; r < 3; r++) v_pc[r] = a.v_points[i * 3 + r];
         }
-        float Wm[9], vW[9];
-        mat3_mul(cam.R, Rm, Wm);
-  #pragma unroll
-        for (int r = 0; r < 3; r++)
-  #pragma unroll
-          for (int c = 0; c < 3; c++) vW[r * 3 + c] = vM[r * 3 + c] * sc[c];
-  #pragma unroll
-        for (int c = 0; c < 3; c++) v_sc[c] += Wm[c] * vM[c] + Wm[3 + c] * vM[3 + c] + Wm[6 + c] * vM[6 + c];
-        mat3_mul_at(cam.R, vW, vRm);  // Rcw^T vW
+#pragma unroll
+        for (int c = 0; c < 3; c++) v_mw[c] = has_cam ? cam.R[c] * v_pc[0] + cam.R[3 + c] * v_pc[1] + cam.R[6 + c] * v_pc[2] : v_pc[c];
+      } else {
+        // ---- phase 2: camera forward (gsplat fully_fused_projection; the visibility decision is
+        // the saved radius, so no culling tests here) ----
+        float Rm[9];
         {
-          float tmp[9];
-          mat3_mul_bt(vW, Rm, tmp);    // vW Rm^T  -> dL/dRcw
-  #pragma unroll
-          for (int r = 0; r < 9; r++) v_view[r] += tmp[r];
-  #pragma unroll
-          for (int r = 0; r < 3; r++) {
-  #pragma unroll
-            for (int c = 0; c < 3; c++) v_view[r * 3 + c] += v_pc[r] * mw[c];
-            v_view[9 + r] += v_pc[r];
+          float Rq[9];
+          quat_to_rotmat(qh[0], qh[1], qh[2], qh[3], Rq);
+          if (isdyn) mat3_mul(Rd, Rq, Rm);
+          else {
+#pragma unroll
+            for (int r = 0; r < 9; r++) Rm[r] = Rq[r];
           }
         }
-      }
-      float v_mw[3];
+        float mw[3] = {mw0[0], mw0[1], mw0[2]};
+        if (a.in.RTs) {
+          const float *RT = a.in.RTs + s * 12;
 #pragma unroll
-      for (int c = 0; c < 3; c++) v_mw[c] = cam.R[c] * v_pc[0] + cam.R[3 + c] * v_pc[1] + cam.R[6 + c] * v_pc[2];
+          for (int r = 0; r < 3; r++) mw[r] = RT[r * 4] * mw0[0] + RT[r * 4 + 1] * mw0[1] + RT[r * 4 + 2] * mw0[2] + RT[r * 4 + 3];
+        }
+        float pc[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) pc[r] = cam.R[r * 3] * mw[0] + cam.R[r * 3 + 1] * mw[1] + cam.R[r * 3 + 2] * mw[2] + cam.t[r];
+        float M[9];  // Rcw Rm diag(sc): the camera-space "sqrt" of the covariance
+        {
+          float Wm[9];
+          mat3_mul(cam.R, Rm, Wm);
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) M[r * 3 + c] = Wm[r * 3 + c] * sc[c];
+        }
+        SB();
+        const float rz = __builtin_amdgcn_rcpf(pc[2]), rz2 = rz * rz, rz3 = rz2 * rz;
+        const float xr = pc[0] * rz, yr = pc[1] * rz;
+        const bool in_x = (xr <= cam.limx) && (xr >= -cam.limx), in_y = (yr <= cam.limy) && (yr >= -cam.limy);
+        const float tx = pc[2] * fminf(cam.limx, fmaxf(-cam.limx, xr)), ty = pc[2] * fminf(cam.limy, fmaxf(-cam.limy, yr));
+        const float J00 = cam.fx * rz, J11 = cam.fy * rz, J02 = -cam.fx * tx * rz2, J12 = -cam.fy * ty * rz2;
+        // ---- phase 3: adjoint of conic = inverse(cov2d_blur), cov2d = J covc J^T ----
+        float w00, w01, w11;
+        {
+          const float A = in_con[0], Bc = in_con[1], C = in_con[2];
+          const float vA = in_vcon[0], vB = 0.5f * in_vcon[1], vC = in_vcon[2];
+          const float t00 = A * vA + Bc * vB, t01 = A * vB + Bc * vC, t10 = Bc * vA + C * vB, t11 = Bc * vB + C * vC;
+          w00 = -(t00 * A + t01 * Bc), w01 = -(t00 * Bc + t01 * C), w11 = -(t10 * Bc + t11 * C);
+        }
+        float vJ00, vJ02, vJ11, vJ12;
+        {
+          const float cxx = M[0] * M[0] + M[1] * M[1] + M[2] * M[2], cxy = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+          const float cxz = M[0] * M[6] + M[1] * M[7] + M[2] * M[8], cyy = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+          const float cyz = M[3] * M[6] + M[4] * M[7] + M[5] * M[8], czz = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+          const float js00 = J00 * cxx + J02 * cxz, js01 = J00 * cxy + J02 * cyz, js02 = J00 * cxz + J02 * czz;  // J covc (2x3)
+          const float js10 = J11 * cxy + J12 * cxz, js11 = J11 * cyy + J12 * cyz, js12 = J11 * cyz + J12 * czz;
+          vJ00 = 2.f * (w00 * js00 + w01 * js10), vJ02 = 2.f * (w00 * js02 + w01 * js12);
+          vJ11 = 2.f * (w01 * js01 + w11 * js11), vJ12 = 2.f * (w01 * js02 + w11 * js12);
+        }
+        SB();
+        float v_pc[3];
+        {
+          const float vm0 = in_vm2[0], vm1 = in_vm2[1];
+          v_pc[0] = cam.fx * rz * vm0;
+          v_pc[1] = cam.fy * rz * vm1;
+          v_pc[2] = -(cam.fx * pc[0] * vm0 + cam.fy * pc[1] * vm1) * rz2 + in_vdep;
+          if (in_x) v_pc[0] += -cam.fx * rz2 * vJ02; else v_pc[2] += -cam.fx * rz3 * vJ02 * tx;
+          if (in_y) v_pc[1] += -cam.fy * rz2 * vJ12; else v_pc[2] += -cam.fy * rz3 * vJ12 * ty;
+          v_pc[2] += -cam.fx * rz2 * vJ00 - cam.fy * rz2 * vJ11 + 2.f * cam.fx * tx * rz3 * vJ02 + 2.f * cam.fy * ty * rz3 * vJ12;
+        }
+        // ---- phase 4: covc = M M^T: v_M = (v_covc + v_covc^T) M, v_covc = J^T w J (symmetric, 6 distinct entries) ----
+        float vW[9];
+        {
+          const float a0 = w00 * J00, a1 = w01 * J11, a2 = w00 * J02 + w01 * J12;  // row 0 of (w J)
+          const float b0 = w01 * J00, b1 = w11 * J11, b2 = w01 * J02 + w11 * J12;  // row 1 of (w J)
+          const float s00 = 2.f * J00 * a0, s01 = J00 * a1 + J11 * b0, s02 = J00 * a2 + (J02 * a0 + J12 * b0);
+          const float s11 = 2.f * J11 * b1, s12 = J11 * b2 + (J02 * a1 + J12 * b1), s22 = 2.f * (J02 * a2 + J12 * b2);
+          float vsc[3] = {0, 0, 0};
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float m0 = M[c], m1 = M[3 + c], m2 = M[6 + c];
+            const float vm0 = s00 * m0 + s01 * m1 + s02 * m2, vm1 = s01 * m0 + s11 * m1 + s12 * m2, vm2 = s02 * m0 + s12 * m1 + s22 * m2;
+            vsc[c] = m0 * vm0 + m1 * vm1 + m2 * vm2;  // = sc[c] * dL/dsc[c]  (M = Wm diag(sc))
+            vW[c] = vm0 * sc[c], vW[3 + c] = vm1 * sc[c], vW[6 + c] = vm2 * sc[c];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; c++) ACC(7 + c, vsc[c]);
+        }
+        SB();
+        // ---- phase 5: view-matrix gradient (dL/dRcw = vW Rm^T + v_pc mw^T, dL/dt = v_pc), instance rotation ----
+        {
+          float tmp[9];
+          mat3_mul_bt(vW, Rm, tmp);
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) ACC(10 + r * 3 + c, tmp[r * 3 + c] + v_pc[r] * mw[c]);
+            ACC(19 + r, v_pc[r]);
+          }
+        }
+        mat3_mul_at(cam.R, vW, vRm);  // Rcw^T vW
+#pragma unroll
+        for (int c = 0; c < 3; c++) v_mw[c] = cam.R[c] * v_pc[0] + cam.R[3 + c] * v_pc[1] + cam.R[6 + c] * v_pc[2];
+        SB();
+      }
       // ---- camera delta ----
       float v_mw0[3] = {v_mw[0], v_mw[1], v_mw[2]};
       if (a.in.RTs) {
+        const float *RT = a.in.RTs + s * 12;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
 #pragma unroll
@@ -240,58 +364,90 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
       // ---- deformation ----
       if (isdyn) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) v_mu[c] += Rd[c] * v_mw0[0] + Rd[3 + c] * v_mw0[1] + Rd[6 + c] * v_mw0[2];
+        for (int c = 0; c < 3; c++) ACC(c, Rd[c] * v_mw0[0] + Rd[3 + c] * v_mw0[1] + Rd[6 + c] * v_mw0[2]);
         float vRd[9];
-        mat3_mul_bt(vRm, Rq, vRd);  // vRm Rq^T
+        if (MODE == MODE_RENDER) {
+          float Rq[9];
+          quat_to_rotmat(qh[0], qh[1], qh[2], qh[3], Rq);
+          mat3_mul_bt(vRm, Rq, vRd);  // vRm Rq^T
+          float tmp[9];
+          mat3_mul_at(Rd, vRm, tmp);  // Rd^T vRm = dL/dRq
+          {
+            float vq[4] = {0, 0, 0, 0};
+            rotmat_adj_to_quat(qh, tmp, vq);
+#pragma unroll
+            for (int c = 0; c < 4; c++) ACC(3 + c, vq[c]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 9; r++) vRd[r] = 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
           for (int c = 0; c < 3; c++) vRd[r * 3 + c] += v_mw0[r] * mu[c];
-        {
-          float tmp[9];
-          mat3_mul_at(Rd, vRm, tmp);  // Rd^T vRm
+        if (MODE == MODE_POSES) {
+          if (a.v_transforms) {  // transforms [.,3,4] = [Rd | transl]
+            const float *vt = a.v_transforms + (a.g_major ? (unsigned)g * S + s : (unsigned)s * G + g) * 12u;
 #pragma unroll
-          for (int r = 0; r < 9; r++) v_Rq[r] += tmp[r];
+            for (int r = 0; r < 3; r++) {
+#pragma unroll
+              for (int c = 0; c < 3; c++) vRd[r * 3 + c] += vt[r * 4 + c];
+              v_mw0[r] += vt[r * 4 + 3];
+            }
+          }
+          if (a.v_quats_out) {  // quats_out = normalize(rotmat_to_unitquat(Rd) (x) qh)  scene_model.py:94-102
+            PoseQ pq;
+            pose_quat(Rd, qh, pq);
+            float vo[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) vo[c] = a.v_quats_out[i * 4 + c];
+            float vq[4] = {0, 0, 0, 0};
+            pose_quat_adj(pq, qh, vo, vRd, vq);
+#pragma unroll
+            for (int c = 0; c < 4; c++) ACC(3 + c, vq[c]);
+          }
         }
-        // Gram-Schmidt adjoint (columns x, y, z of Rd)
+        SB();
+        // Gram-Schmidt adjoint (columns x, y, z of Rd; transforms.py:41-53)
+        const float gx[3] = {Rd[0], Rd[3], Rd[6]}, gy[3] = {Rd[1], Rd[4], Rd[7]};
         float vx[3] = {vRd[0], vRd[3], vRd[6]}, vy[3] = {vRd[1], vRd[4], vRd[7]}, vz[3] = {vRd[2], vRd[5], vRd[8]};
         // z = x cross y
-        vx[0] += gs.y[1] * vz[2] - gs.y[2] * vz[1];
-        vx[1] += gs.y[2] * vz[0] - gs.y[0] * vz[2];
-        vx[2] += gs.y[0] * vz[1] - gs.y[1] * vz[0];
-        vy[0] += vz[1] * gs.x[2] - vz[2] * gs.x[1];
-        vy[1] += vz[2] * gs.x[0] - vz[0] * gs.x[2];
-        vy[2] += vz[0] * gs.x[1] - vz[1] * gs.x[0];
+        vx[0] += gy[1] * vz[2] - gy[2] * vz[1];
+        vx[1] += gy[2] * vz[0] - gy[0] * vz[2];
+        vx[2] += gy[0] * vz[1] - gy[1] * vz[0];
+        vy[0] += vz[1] * gx[2] - vz[2] * gx[1];
+        vy[1] += vz[2] * gx[0] - vz[0] * gx[2];
+        vy[2] += vz[0] * gx[1] - vz[1] * gx[0];
         // y = bp * inv_nb
         float vbp[3];
         {
-          const bool clamped = gs.inv_nb >= 1e12f;
-          const float dty = clamped ? 0.f : (vy[0] * gs.y[0] + vy[1] * gs.y[1] + vy[2] * gs.y[2]);
+          const bool clamped = gs_inv_nb >= 1e12f;
+          const float dty = clamped ? 0.f : (vy[0] * gy[0] + vy[1] * gy[1] + vy[2] * gy[2]);
 #pragma unroll
-          for (int c = 0; c < 3; c++) vbp[c] = (vy[c] - dty * gs.y[c]) * gs.inv_nb;
+          for (int c = 0; c < 3; c++) vbp[c] = (vy[c] - dty * gy[c]) * gs_inv_nb;
         }
         // bp = b - (b.x) x
-        const float vbx = vbp[0] * gs.x[0] + vbp[1] * gs.x[1] + vbp[2] * gs.x[2];
-        const float *bb = v9 + 6;
+        const float vbx = vbp[0] * gx[0] + vbp[1] * gx[1] + vbp[2] * gx[2];
         float vb[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          vb[c] = vbp[c] - vbx * gs.x[c];
-          vx[c] += -gs.d * vbp[c] - vbx * bb[c];
+          vb[c] = vbp[c] - vbx * gx[c];
+          vx[c] += -gs_d * vbp[c] - vbx * bb[c];
         }
         // x = a * inv_na
         float va_[3];
         {
-          const bool clamped = gs.inv_na >= 1e12f;
-          const float dtx = clamped ? 0.f : (vx[0] * gs.x[0] + vx[1] * gs.x[1] + vx[2] * gs.x[2]);
+          const bool clamped = gs_inv_na >= 1e12f;
+          const float dtx = clamped ? 0.f : (vx[0] * gx[0] + vx[1] * gx[1] + vx[2] * gx[2]);
 #pragma unroll
-          for (int c = 0; c < 3; c++) va_[c] = (vx[c] - dtx * gs.x[c]) * gs.inv_na;
+          for (int c = 0; c < 3; c++) va_[c] = (vx[c] - dtx * gx[c]) * gs_inv_na;
         }
         vec[0] = v_mw0[0], vec[1] = v_mw0[1], vec[2] = v_mw0[2];
         vec[3] = va_[0], vec[4] = va_[1], vec[5] = va_[2];
         vec[6] = vb[0], vec[7] = vb[1], vec[8] = vb[2];
+        SB();
         // coefficient gradients: v_c[k] += B_s[k] . vec[0:9]
-        const float *B = Bs + s * K * 9;
         for (int k = 0; k < K; k++) {
           float acc = 0.f;
 #pragma unroll
@@ -300,50 +456,49 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < 3; c++) v_mu[c] += v_mw0[c];
+        for (int c = 0; c < 3; c++) ACC(c, v_mw0[c]);
+        if (MODE == MODE_RENDER) {
+          float vq[4] = {0, 0, 0, 0};
+          rotmat_adj_to_quat(qh, vRm, vq);
 #pragma unroll
-        for (int r = 0; r < 9; r++) v_Rq[r] += vRm[r];
+          for (int c = 0; c < 4; c++) ACC(3 + c, vq[c]);
+        }
+        else if (a.v_quats_out) {  // static Gaussian: quats_out = normalize(q)
+#pragma unroll
+          for (int c = 0; c < 4; c++) ACC(3 + c, a.v_quats_out[i * 4 + c]);
+        }
       }
+      }  // visible
     }
-    // ---- block column sums for sub-sample s: 9K weighted by cf, 12 plain ----
-    // Every wave reduces its 64 lanes with the permlane-swap ladder (common.h) and leaves its totals in its own
-    // psum segment; the 4 segments are then added in fixed order -> deterministic.  (The first version walked the 256
-    // per-thread vectors through LDS: 2 LDS reads per term, 25 % of the kernel.)
-    if (dyn || a.in.RTs) {
-      const int nk = dyn ? K * 9 : 0, no = nk + 12, nop = no + 1;  // +1: wave_sum_store's dump slot
-      const int lane = tid & 63, seg = tid >> 6;
-      // double-buffered over s: the buffer written now was last read two sub-samples ago, before the barrier of s - 1,
-      // so ONE barrier per sub-sample (writes -> reads) is enough
-      float *pb = psum + (s & 1) * 4 * nop;
-      float *mine = pb + seg * nop;
+    SB();
+    // ---- shared gradients of sub-sample s: 9K column sums weighted by cf + 12 plain, over THIS wave's 64 Gaussians ----
+    if (shared) {
       if (dyn) {
-        if (dyn_block && K <= 8) {  // few bases: K x (9 multiplies + a 9-value wave reduction) on the VALU
+        if (dyn_block && !MFMA) {  // few bases: K x (9 multiplies + a 9-value wave reduction) on the VALU
           for (int k = 0; k < K; k++) {
-            const float c = cf[tid * KP + k];
+            const float c = cf[lane * KP + k];
             float p[9];
 #pragma unroll
             for (int jj = 0; jj < 9; jj++) p[jj] = c * vec[jj];
-            wave_sum_store(p, mine + k * 9, lane);
+            wave_sum_store(p, mine, k * 9, lane);
           }
         } else if (dyn_block) {
-          // v_Bs[k][j] = sum over the wave's 64 Gaussians of coef[g][k] * vec[g][j]: a [K x 64] x [64 x 9] product.  On the
+          // v_Bs[k][j] = sum over the wave's 64 Gaussians of coef[g][k] * vec[g][j]: a [K x 64] x [64 x 9] product on the
           // matrix pipe: 16 v_mfma_f32_16x16x4_f32 per 16 bases (A = coefficients, B = vec, both read from LDS in the
-          // operand layout); exact f32, fixed order.  Measured (MI355X): K = 6 167 vs 158 us on the VALU (10 of the 16
-          // rows idle, a dependent MFMA chain at 2 waves per SIMD), K = 12 1011 vs 1095, K = 20 111 vs 119 - hence K > 8.
-          // (Four independent accumulator chains need 19 more registers: 1 wave per SIMD, 246 us.)
+          // operand layout); exact f32, fixed order.
           typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
           for (int jj = 0; jj < 9; jj++) svec[tid * 9 + jj] = vec[jj];
           __builtin_amdgcn_wave_barrier();  // a wave only reads the rows of its own 64 lanes
-          const int wbase = tid & ~63, ln = lane & 15, lk = lane >> 4;
+          const int ln = lane & 15, lk = lane >> 4;
           for (int mt = 0; mt < K; mt += 16) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const bool am = mt + ln < K;
 #pragma unroll 4
             for (int kk = 0; kk < 16; kk++) {
-              const int src = wbase + 4 * kk + lk;  // the Gaussian (lane of this wave) this operand element belongs to
+              const int src = 4 * kk + lk;  // the Gaussian (lane of this wave) this operand element belongs to
               const float av = am ? cf[src * KP + mt + ln] : 0.f;
-              const float bv = ln < 9 ? svec[src * 9 + ln] : 0.f;
+              const float bv = ln < 9 ? svec[(slot * 64 + src) * 9 + ln] : 0.f;
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
             }
             if (ln < 9) {
@@ -354,7 +509,6 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
               }
             }
           }
-          __builtin_amdgcn_wave_barrier();
         } else {
           for (int o = lane; o < nk; o += 64) mine[o] = 0.f;
         }
@@ -363,42 +517,70 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
         float q[12];
 #pragma unroll
         for (int r = 0; r < 12; r++) q[r] = vec[9 + r];
-        wave_sum_store(q, mine + nk, lane);
+        wave_sum_store(q, mine, nk, lane);
       }
-      __syncthreads();
-      for (int o = tid; o < no; o += BLK)
-        part[s * no + o] = (pb[o] + pb[nop + o]) + (pb[2 * nop + o] + pb[3 * nop + o]);
+      __builtin_amdgcn_wave_barrier();
+      if (a.persist) {
+        for (int o = lane; o < no; o += 64) part[s * no + o] += mine[o];
+      } else {
+        for (int o = lane; o < no; o += 64) part[s * no + o] = mine[o];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
+    if (more) bases_store(bsl + (slot * 2 + (cur ^ 1)) * nk4);
   }
 
-  // ---- viewmat partials (12 plain column sums): the same per-wave ladder + fixed-order sum of the 4 segments ----
+  // ---- viewmat partials (12 plain column sums): per-wave ladder + fixed-order sum of the 4 slots ----
   {
-    const int nk = dyn ? K * 9 : 0;
-    __syncthreads();  // the last sub-sample's psum has been consumed
-    wave_sum_store(v_view, psum + (tid >> 6) * 13, tid & 63);
-    __syncthreads();
-    if (tid < 12) part[S * (nk + 12) + tid] = (psum[tid] + psum[13 + tid]) + (psum[26 + tid] + psum[39 + tid]);
+    float v_view[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) v_view[c] = ac[10 + c];
+    wave_sum_store(v_view, mine, 0, lane);
+  }
+  __syncthreads();
+  if (tid < 12) {
+    const float v = (red[tid] + red[nop + tid]) + (red[2 * nop + tid] + red[3 * nop + tid]);
+    if (a.persist) part[S * no + tid] += v;
+    else part[S * no + tid] = v;
   }
 
-  if (!active) return;
-  // ---- per-Gaussian leaves ----
-  a.g.v_means[g * 3] = v_mu[0], a.g.v_means[g * 3 + 1] = v_mu[1], a.g.v_means[g * 3 + 2] = v_mu[2];
-  if (!pts) {
-    const float w = qh[0], x = qh[1], y = qh[2], z = qh[3];
-    const float *vR = v_Rq;
-    float vq[4];
-    vq[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
-    vq[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[3] + vR[1]) + z * (vR[6] + vR[2]) + w * (vR[7] - vR[5]));
-    vq[2] = 2.f * (x * (vR[3] + vR[1]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[7] + vR[5]) + w * (vR[2] - vR[6]));
-    vq[3] = 2.f * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
-    const float dot = vq[0] * w + vq[1] * x + vq[2] * y + vq[3] * z;
-    float4 o4 = make_float4((vq[0] - dot * w) * inv_qn, (vq[1] - dot * x) * inv_qn, (vq[2] - dot * y) * inv_qn,
-                            (vq[3] - dot * z) * inv_qn);
-    *reinterpret_cast<float4 *>(a.g.v_quats + (size_t)g * 4) = o4;
-  }
-  if (!pts) {
+  if (active) {
+  // sum of the 4 slots' accumulators of Gaussian `lane`, fixed order
+  auto slots4 = [&](int c) {
+    return (accs[lane * NACC + c] + accs[(64 + lane) * NACC + c]) + (accs[(128 + lane) * NACC + c] + accs[(192 + lane) * NACC + c]);
+  };
+  // ---- per-Gaussian leaves: the block's 4 waves split the tensors ----
+  if (slot == 0) {
+    a.g.v_means[g * 3] = slots4(0), a.g.v_means[g * 3 + 1] = slots4(1), a.g.v_means[g * 3 + 2] = slots4(2);
+    if (MODE == MODE_RENDER) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) a.g.v_scales[g * 3 + j] = raw ? v_sc[j] * sc[j] : v_sc[j];
+      for (int j = 0; j < 3; j++) {
+        const float v = slots4(7 + j);  // accumulated as sc * dL/dsc
+        a.g.v_scales[g * 3 + j] = raw ? v : v / sc[j];
+      }
+    }
+  } else if (slot == 1) {
+    if (need_q && a.g.v_quats) {  // adjoint of q / max(|q|, eps)
+      const float w = qh[0], x = qh[1], y = qh[2], z = qh[3];
+      const float vq0 = slots4(3), vq1 = slots4(4), vq2 = slots4(5), vq3 = slots4(6);
+      const float dot = vq0 * w + vq1 * x + vq2 * y + vq3 * z;
+      float4 o4 = make_float4((vq0 - dot * w) * inv_qn, (vq1 - dot * x) * inv_qn, (vq2 - dot * y) * inv_qn,
+                              (vq3 - dot * z) * inv_qn);
+      *reinterpret_cast<float4 *>(a.g.v_quats + (size_t)g * 4) = o4;
+    }
+  } else if (slot == 2) {
+    if (isdyn) {  // softmax adjoint
+      const bool act = MODE == MODE_POSES && !raw;
+      float dot = 0.f;
+      for (int k = 0; k < K; k++) {
+        const float v = (vcf[lane * KP + k] + vcf[(64 + lane) * KP + k]) + (vcf[(128 + lane) * KP + k] + vcf[(192 + lane) * KP + k]);
+        vcf[lane * KP + k] = v;  // (only this lane touches row `lane` from here on)
+        dot += cf[lane * KP + k] * v;
+      }
+      for (int k = 0; k < K; k++)
+        a.g.v_motion_coefs[(size_t)g * K + k] = act ? vcf[lane * KP + k] : cf[lane * KP + k] * (vcf[lane * KP + k] - dot);
+    }
+  } else if (MODE == MODE_RENDER) {
     const float o = a.opac_act[g];
     const float vo = a.v_opac_act[g];
     a.g.v_opacities[g] = raw ? vo * o * (1.f - o) : vo;
@@ -412,25 +594,35 @@ __global__ void __launch_bounds__(BLK) k_project_bwd(const BwdArgs a) {
       a.g.v_colors[(size_t)g * D + ch] = v;
     }
   }
-  if (isdyn) {  // softmax adjoint
-    float dot = 0.f;
-    for (int k = 0; k < K; k++) dot += cf[tid * KP + k] * vcf[tid * KP + k];
-    for (int k = 0; k < K; k++)
-      a.g.v_motion_coefs[(size_t)g * K + k] = cf[tid * KP + k] * (vcf[tid * KP + k] - dot);
+  }  // active
+  __syncthreads();  // cf / vcf / accs / red are rewritten by the next group
+  }  // groups
+  if (a.persist) {
+    float *dst = a.g.partials + (size_t)blockIdx.x * a.n_shared;
+    for (int o = tid; o < a.n_shared; o += BLK) dst[o] = wacc[o];
   }
 }
 
-// sum the per-block partial vectors (deterministic): one workgroup per 4 outputs, 64 lanes stride the blocks,
-// fixed-shape tree over the 64 partial sums.
+// Sum the per-block partial vectors in a fixed order (deterministic), two coalesced passes: thread o of chunk c adds its
+// output's values of the chunk's blocks one after the other (neighbouring lanes read neighbouring floats), then one more
+// launch of the same kernel adds the RCH chunk sums.  (Round 2 had a wave stride over the blocks of one output: 4-byte
+// reads n floats apart - 30 us once the 64-Gaussian blocks made 4x as many partials.)
+constexpr int RCH = 64;
 __global__ void __launch_bounds__(256) k_reduce_partials(const float *partials, int n_blocks, int n, float *out) {
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  float acc = 0.f;
-  if (o < n)
-    for (int b = lane; b < n_blocks; b += 64) acc += partials[(size_t)b * n + o];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-  if (o < n && lane == 0) out[o] = acc;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  const int per = (n_blocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(b0 + per, n_blocks);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    a0 += partials[(size_t)b * n + o];
+    a1 += partials[(size_t)(b + 1) * n + o];
+    a2 += partials[(size_t)(b + 2) * n + o];
+    a3 += partials[(size_t)(b + 3) * n + o];
+  }
+  for (; b < b1; b++) a0 += partials[(size_t)b * n + o];
+  out[(size_t)blockIdx.y * n + o] = (a0 + a1) + (a2 + a3);
 }
 
 // scatter the reduced shared gradients: v_Bs -> rots / transls / times ; camera deltas ; viewmat.
@@ -497,21 +689,63 @@ int n_shared_of(const D4gsDims *d) { return d->S * ((d->G > 0 ? d->K * 9 : 0) + 
 
 }  // namespace
 
-extern "C" size_t d4gs_bwd_partials_elems(const D4gsDims *d) {
-  const size_t blocks = ((size_t)d->N + BLK - 1) / BLK;
-  return (blocks + 1) * (size_t)n_shared_of(d);
+constexpr int PERSIST_BLOCKS = 1024;      // 256 CUs x 4 resident blocks; a constant, so the summation order (hence every bit of
+                                          // the result) does not depend on the device the kernel runs on
+constexpr int PERSIST_MAX_SHARED = 8192;  // floats of LDS a block may spend on its shared-gradient sums
+static bool use_persist(const D4gsDims *d) { return n_shared_of(d) <= PERSIST_MAX_SHARED; }
+static size_t partial_blocks(const D4gsDims *d) {
+  const size_t groups = ((size_t)d->N + GPB - 1) / GPB;
+  return use_persist(d) && groups > PERSIST_BLOCKS ? PERSIST_BLOCKS : groups;
 }
 
-static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGrads *grads, hipStream_t stream);
+extern "C" size_t d4gs_bwd_partials_elems(const D4gsDims *d) {
+  return (partial_blocks(d) + RCH + 1) * (size_t)n_shared_of(d);
+}
 
-int d4gs_points_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points, const D4gsLeafGrads *grads,
-                         hipStream_t stream) {
+template <int MODE>
+static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGrads *grads, hipStream_t stream) {
+  a.n_shared = n_shared_of(dims);
+  a.persist = use_persist(dims) ? 1 : 0;
+  const int K = dims->G > 0 ? dims->K : 0;
+  const int KP = K | 1;
+  const size_t nk = (size_t)K * 9;
+  size_t lds = sizeof(float) * ((size_t)GPB * KP + (size_t)BLK * KP + 2 * SLOTS * ((nk + 3) & ~(size_t)3) + SLOTS * (nk + 13) +
+                                (size_t)BLK * NACC + (K > 8 ? (size_t)BLK * 9 : 0) + (a.persist ? (size_t)a.n_shared : 0));
+  if (lds > 160 * 1024) {
+    d4gs_set_error("project_bwd: LDS budget exceeded (K=%d)", dims->K);
+    return D4GS_EINVAL;
+  }
+  if (lds > 64 * 1024) {  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
+    if (K > 8) (void)hipFuncSetAttribute((const void *)k_project_bwd<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    else (void)hipFuncSetAttribute((const void *)k_project_bwd<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int blocks = (int)partial_blocks(dims);
+  const char *name = MODE == MODE_RENDER ? "k_project_bwd" : "k_project_bwd[poses]";
+  if (K > 8) D4GS_LAUNCH(name, (k_project_bwd<MODE, true>), dim3(blocks), dim3(BLK), lds, stream, a);
+  else D4GS_LAUNCH(name, (k_project_bwd<MODE, false>), dim3(blocks), dim3(BLK), lds, stream, a);
+  int rc = d4gs_check_launch(name);
+  if (rc) return rc;
+  float *red2 = grads->partials + (size_t)blocks * a.n_shared;  // [RCH][n_shared] chunk sums, then [n_shared] totals
+  float *red = red2 + (size_t)RCH * a.n_shared;
+  D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256, RCH), dim3(256), 0, stream,
+              (const float *)grads->partials, blocks, a.n_shared, red2);
+  D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256, 1), dim3(256), 0, stream,
+              (const float *)red2, RCH, a.n_shared, red);
+  int fin = dims->G > 0 ? dims->K * dims->T * 9 : 0;
+  if (fin < dims->S * 12) fin = dims->S * 12;
+  if (fin < 16) fin = 16;
+  D4GS_LAUNCH("k_finish", k_finish, dim3((fin + 255) / 256), dim3(256), 0, stream, a, (const float *)red);
+  return d4gs_check_launch("k_finish");
+}
+
+int d4gs_poses_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *v_out, const D4gsLeafGrads *grads,
+                        hipStream_t stream) {
   BwdArgs a{};
   a.d = *dims;
   a.in = *in;
   a.g = *grads;
-  a.v_points = v_points;
-  return launch_project_bwd(a, dims, grads, stream);
+  a.v_points = v_out->means, a.v_quats_out = v_out->quats, a.v_transforms = v_out->transforms, a.g_major = v_out->g_major;
+  return launch_project_bwd<MODE_POSES>(a, dims, grads, stream);
 }
 
 int d4gs_project_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *proj, const float *v_means2d,
@@ -523,32 +757,5 @@ int d4gs_project_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   a.radii = proj->radii, a.conics = proj->conics, a.ctab = proj->ctab, a.opac_act = proj->opac_act;
   a.v_means2d = v_means2d, a.v_conics = v_conics, a.v_depths = v_depths, a.v_opac_act = v_opac_act, a.v_ctab = v_ctab;
   a.g = *grads;
-  a.v_points = nullptr;
-  return launch_project_bwd(a, dims, grads, stream);
-}
-
-static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGrads *grads, hipStream_t stream) {
-  a.n_shared = n_shared_of(dims);
-  const int K = dims->G > 0 ? dims->K : 0;
-  const int KP = K | 1;
-  size_t lds = sizeof(float) * ((((size_t)dims->S * K * 9 + 3) & ~(size_t)3) + 2 * (size_t)BLK * KP +
-                                8 * ((size_t)K * 9 + 13) + (size_t)BLK * 9);
-  if (lds > 160 * 1024) {
-    d4gs_set_error("project_bwd: LDS budget exceeded (S=%d K=%d)", dims->S, dims->K);
-    return D4GS_EINVAL;
-  }
-  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
-  (void)hipFuncSetAttribute((const void *)k_project_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const int blocks = (dims->N + BLK - 1) / BLK;
-  D4GS_LAUNCH("k_project_bwd", k_project_bwd, dim3(blocks), dim3(BLK), lds, stream, a);
-  int rc = d4gs_check_launch("k_project_bwd");
-  if (rc) return rc;
-  float *red = grads->partials + (size_t)blocks * a.n_shared;
-  D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 3) / 4), dim3(256), 0, stream, grads->partials, blocks,
-                     a.n_shared, red);
-  int fin = dims->G > 0 ? dims->K * dims->T * 9 : 0;
-  if (fin < dims->S * 12) fin = dims->S * 12;
-  if (fin < 16) fin = 16;
-  D4GS_LAUNCH("k_finish", k_finish, dim3((fin + 255) / 256), dim3(256), 0, stream, a, (const float *)red);
-  return d4gs_check_launch("k_finish");
+  return launch_project_bwd<MODE_RENDER>(a, dims, grads, stream);
 }

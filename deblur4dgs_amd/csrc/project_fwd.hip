@@ -22,7 +22,6 @@ struct FwdArgs {
   D4gsProjOut out;
   int tw, th;
   int count_apart;  // 1: k_count_tiles does the tile counting / ranking (LDS-aggregated), 0: this kernel's global atomics
-  float *points;  // non-null: "points only" mode (track channels, a11): write the camera-space mean [S,N,3] and stop
 };
 
 // time-blended bases: Bs[s][k][0:3] = transl, [3:9] = 6-D rotation   (params.py:152-177; w uses the clamped floor)
@@ -66,13 +65,10 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
   const bool active = g < N;
   const bool raw = d.flags & D4GS_RAW_PARAMS;
   float mu[3] = {0, 0, 0}, Rq[9], sc[3] = {1, 1, 1}, opac = 0.f;
-  const bool pts = a.points != nullptr;
   if (active) {
     mu[0] = a.in.means[g * 3];
     mu[1] = a.in.means[g * 3 + 1];
     mu[2] = a.in.means[g * 3 + 2];
-  }
-  if (active && !pts) {
     const float4 q = *reinterpret_cast<const float4 *>(a.in.quats + (size_t)g * 4);
     float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
     quat_to_rotmat(q.x * inv, q.y * inv, q.z * inv, q.w * inv, Rq);
@@ -130,7 +126,7 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       float Rd[9] = {gs.x[0], gs.y[0], gs.z[0], gs.x[1], gs.y[1], gs.z[1], gs.x[2], gs.y[2], gs.z[2]};
 #pragma unroll
       for (int i = 0; i < 3; i++) mw[i] = Rd[i * 3] * mu[0] + Rd[i * 3 + 1] * mu[1] + Rd[i * 3 + 2] * mu[2] + v9[i];
-      if (!pts) mat3_mul(Rd, Rq, Rm);
+      mat3_mul(Rd, Rq, Rm);
     } else {
 #pragma unroll
       for (int i = 0; i < 3; i++) mw[i] = mu[i];
@@ -145,12 +141,6 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       mw[0] = t0, mw[1] = t1, mw[2] = t2;
     }
     const size_t i = (size_t)s * N + g;
-    if (pts) {  // scene_model.py:258-289: positions at the target times in the target cameras
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-        a.points[i * 3 + r] = cam.R[r * 3] * mw[0] + cam.R[r * 3 + 1] * mw[1] + cam.R[r * 3 + 2] * mw[2] + cam.t[r];
-      continue;
-    }
     ProjOut p;
     project_instance(cam, mw, Rm, sc, d, p);
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
@@ -185,6 +175,131 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
     float4 *gp = reinterpret_cast<float4 *>(a.out.geom + i * D4GS_GEOM_STRIDE);
     gp[0] = g0;
     gp[1] = g1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a4/a5 + a11: SceneModel.compute_transforms / compute_poses_fg / compute_poses_all (flow3d/scene_model.py:58-120) and the
+// track-channel positions (scene_model.py:258-289) for B = S times.  A block owns 64 Gaussians, its 4 waves are 4 time
+// slots (time b = slot, slot + 4, ...): the time is wave-uniform, its blended bases one small LDS slab per wave - any B.
+// ---------------------------------------------------------------------------------------------------
+constexpr int POSE_GPB = 64, POSE_SLOTS = 4;
+struct PosesArgs {
+  D4gsDims d;
+  D4gsProjIn in;
+  D4gsPoses out;
+};
+__global__ void __launch_bounds__(POSE_GPB * POSE_SLOTS) k_poses_fwd(const PosesArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const D4gsDims &d = a.d;
+  const int N = d.N, G = d.G, S = d.S;
+  const int K = G > 0 ? d.K : 0, KP = K | 1, nk = K * 9, nk4 = (nk + 3) & ~3;
+  float *cf = smem;                    // [64][KP]
+  float *bsl = cf + POSE_GPB * KP;     // [4][nk4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x * POSE_GPB + lane;
+  const bool dyn_block = (blockIdx.x * POSE_GPB) < G;
+  const bool active = g < N, isdyn = active && g < G;
+  const bool has_cam = a.in.viewmat != nullptr;
+  Cam cam;
+  if (has_cam) cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
+  float mu[3] = {0, 0, 0}, qh[4] = {1, 0, 0, 0};
+  if (active) mu[0] = a.in.means[g * 3], mu[1] = a.in.means[g * 3 + 1], mu[2] = a.in.means[g * 3 + 2];
+  if (active && a.out.quats) {
+    const float4 q = *reinterpret_cast<const float4 *>(a.in.quats + (size_t)g * 4);
+    const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    qh[0] = q.x * inv, qh[1] = q.y * inv, qh[2] = q.z * inv, qh[3] = q.w * inv;
+  }
+  if (dyn_block && slot == 0) {
+    for (int k = 0; k < K; k++) cf[lane * KP + k] = 0.f;
+    if (isdyn && !(d.flags & D4GS_RAW_PARAMS)) {  // activated coefficients (MotionBases.compute_transforms' own signature)
+      for (int k = 0; k < K; k++) cf[lane * KP + k] = a.in.motion_coefs[(size_t)g * K + k];
+    } else if (isdyn) {  // softmax(motion_coefs)  params.py:43
+      const float *mc = a.in.motion_coefs + (size_t)g * K;
+      float m = -INFINITY;
+      for (int k = 0; k < K; k++) m = fmaxf(m, mc[k]);
+      float sum = 0.f;
+      for (int k = 0; k < K; k++) {
+        float e = expf(mc[k] - m);
+        cf[lane * KP + k] = e;
+        sum += e;
+      }
+      float is = 1.f / sum;
+      for (int k = 0; k < K; k++) cf[lane * KP + k] *= is;
+    }
+  }
+  __syncthreads();
+  float *B = bsl + slot * nk4;
+  for (int s = slot; s < S; s += POSE_SLOTS) {
+    if (dyn_block) {
+      const int T = d.T;
+      const float t = a.in.times[s];
+      const float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));
+      const float cfl = fminf(fmaxf(ceilf(t), 0.f), (float)(T - 1));
+      const float w = t - ff;
+      const int f = (int)ff, c = (int)cfl;
+      for (int idx = lane; idx < nk; idx += 64) {
+        const int k = idx / 9, j = idx - k * 9;
+        float vf, vc;
+        if (j < 3) {
+          vf = a.in.transls[(k * T + f) * 3 + j];
+          vc = a.in.transls[(k * T + c) * 3 + j];
+        } else {
+          vf = a.in.rots[(k * T + f) * 6 + j - 3];
+          vc = a.in.rots[(k * T + c) * 6 + j - 3];
+        }
+        B[idx] = (1.f - w) * vf + w * vc;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (active) {
+      const size_t i = a.out.g_major ? (size_t)g * S + s : (size_t)s * N + g;
+      float mw[3] = {mu[0], mu[1], mu[2]}, qo[4] = {qh[0], qh[1], qh[2], qh[3]};
+      if (isdyn) {
+        float v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < K; k++) {
+          const float c = cf[lane * KP + k];
+#pragma unroll
+          for (int j = 0; j < 9; j++) v9[j] += c * B[k * 9 + j];
+        }
+        GS6 gs;
+        gram_schmidt(v9 + 3, gs);
+        const float Rd[9] = {gs.x[0], gs.y[0], gs.z[0], gs.x[1], gs.y[1], gs.z[1], gs.x[2], gs.y[2], gs.z[2]};
+#pragma unroll
+        for (int r = 0; r < 3; r++) mw[r] = Rd[r * 3] * mu[0] + Rd[r * 3 + 1] * mu[1] + Rd[r * 3 + 2] * mu[2] + v9[r];
+        if (a.out.transforms) {
+          float *tp = a.out.transforms + (a.out.g_major ? (size_t)g * S + s : (size_t)s * G + g) * 12;
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+            *reinterpret_cast<float4 *>(tp + r * 4) = make_float4(Rd[r * 3], Rd[r * 3 + 1], Rd[r * 3 + 2], v9[r]);
+        }
+        if (a.out.quats) {
+          PoseQ pq;
+          pose_quat(Rd, qh, pq);
+#pragma unroll
+          for (int c = 0; c < 4; c++) qo[c] = pq.out[c];
+        }
+      }
+      if (a.out.quats) *reinterpret_cast<float4 *>(a.out.quats + i * 4) = make_float4(qo[0], qo[1], qo[2], qo[3]);
+      if (a.out.means) {
+        if (a.in.RTs) {  // target camera / camera delta (means only)
+          const float *RT = a.in.RTs + s * 12;
+          const float t0 = RT[0] * mw[0] + RT[1] * mw[1] + RT[2] * mw[2] + RT[3];
+          const float t1 = RT[4] * mw[0] + RT[5] * mw[1] + RT[6] * mw[2] + RT[7];
+          const float t2 = RT[8] * mw[0] + RT[9] * mw[1] + RT[10] * mw[2] + RT[11];
+          mw[0] = t0, mw[1] = t1, mw[2] = t2;
+        }
+        if (has_cam) {
+          const float t0 = cam.R[0] * mw[0] + cam.R[1] * mw[1] + cam.R[2] * mw[2] + cam.t[0];
+          const float t1 = cam.R[3] * mw[0] + cam.R[4] * mw[1] + cam.R[5] * mw[2] + cam.t[1];
+          const float t2 = cam.R[6] * mw[0] + cam.R[7] * mw[1] + cam.R[8] * mw[2] + cam.t[2];
+          mw[0] = t0, mw[1] = t1, mw[2] = t2;
+        }
+        a.out.means[i * 3] = mw[0], a.out.means[i * 3 + 1] = mw[1], a.out.means[i * 3 + 2] = mw[2];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the slab is rewritten in the next pass
   }
 }
 
@@ -365,22 +480,16 @@ static size_t fwd_lds_bytes(const D4gsDims *dims) {
   return sizeof(float) * (((size_t)dims->S * dims->K * 9 + 3) & ~(size_t)3) + sizeof(float) * (size_t)dims->K * D4GS_PROJ_BLOCK;
 }
 
-int d4gs_points_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, float *points, hipStream_t stream) {
-  FwdArgs a;
+int d4gs_poses_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *out, hipStream_t stream) {
+  PosesArgs a;
   a.d = *dims;
   a.in = *in;
-  a.out = D4gsProjOut{};
-  a.tw = a.th = 0;
-  a.points = points;
-  a.count_apart = 0;
-  const size_t lds = fwd_lds_bytes(dims);
-  if (lds > 64 * 1024) {
-    d4gs_set_error("S*K too large for the LDS-resident bases (S=%d K=%d)", dims->S, dims->K);
-    return D4GS_EINVAL;
-  }
-  const int blocks = (dims->N + D4GS_PROJ_BLOCK - 1) / D4GS_PROJ_BLOCK;
-  D4GS_LAUNCH("k_project_fwd[points]", k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
-  return d4gs_check_launch("k_project_fwd[points]");
+  a.out = *out;
+  const int K = dims->G > 0 ? dims->K : 0;
+  const size_t lds = sizeof(float) * ((size_t)POSE_GPB * (K | 1) + POSE_SLOTS * (((size_t)K * 9 + 3) & ~(size_t)3));
+  const int blocks = (dims->N + POSE_GPB - 1) / POSE_GPB;
+  D4GS_LAUNCH("k_poses_fwd", k_poses_fwd, dim3(blocks), dim3(POSE_GPB * POSE_SLOTS), lds, stream, a);
+  return d4gs_check_launch("k_poses_fwd");
 }
 
 int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, hipStream_t stream) {
@@ -388,7 +497,6 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   a.d = *dims;
   a.in = *in;
   a.out = *out;
-  a.points = nullptr;
   a.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
   a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   const int64_t n_inst = (int64_t)dims->S * dims->N;

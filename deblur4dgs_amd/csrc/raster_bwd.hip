@@ -58,167 +58,6 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return v;
 }
 
-template <int D, bool DEPTH>
-__global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
-  constexpr int NCH = D + (DEPTH ? 1 : 0);
-  constexpr int DP = (D + 3) & ~3;
-  constexpr int DV = DP / 4;
-  constexpr int R = 6 + NCH;
-  constexpr int RP = (R + 1) | 1;  // odd LDS row stride with >= 1 pad slot (wave_sum_store's dump slot)
-  __shared__ float4 sg0[64];
-  __shared__ float4 sg1[64];
-  __shared__ float4 scol[64 * DV];
-  __shared__ float sgrad[64 * RP];
-
-  if (lists_overflowed(a.n_dev, a.cap, a.max_hint)) return;
-  const int n_tiles_s = a.tw * a.th;
-  const int n_tiles = a.S * n_tiles_s;
-  const int t = xcd_remap_b(blockIdx.x, n_tiles);
-  if (t >= n_tiles) return;
-  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
-  if (end <= start) return;
-  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
-  const int ty = tl / a.tw, tx = tl - ty * a.tw;
-  const int lane = threadIdx.x;
-  const int x0 = tx * D4GS_TILE + 2 * (lane & 7), y0 = ty * D4GS_TILE + 2 * (lane >> 3);
-
-  float pxf[4], pyf[4], T[4], Tfin[4], va[4], vo[4][NCH], bsum[4];
-  int last[4];
-  int hi = start - 1;
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
-    const int x = x0 + (p & 1), y = y0 + (p >> 1);
-    const bool inside = x < a.width && y < a.height;
-    pxf[p] = (float)x + 0.5f;
-    pyf[p] = (float)y + 0.5f;
-    last[p] = -1;
-    Tfin[p] = 1.f;
-    va[p] = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; c++) vo[p][c] = 0.f;
-    bsum[p] = 0.f;
-    if (inside) {
-      const size_t pix = ((size_t)s * a.height + y) * a.width + x;
-      last[p] = a.last_ids[pix];
-      const float al = a.alphas[pix];
-      Tfin[p] = a.final_T[pix];
-      const float *vp = a.v_out + pix * NCH;
-#pragma unroll
-      for (int c = 0; c < NCH; c++) vo[p][c] = vp[c];
-      float v_al = a.v_alphas ? a.v_alphas[pix] : 0.f;
-      if (DEPTH && a.ed) {  // out_d = raw_d / max(alpha, 1e-10)
-        const float den = fmaxf(al, 1e-10f);
-        const float vd = vo[p][D];
-        if (al >= 1e-10f) v_al -= vd * a.out[pix * NCH + D] / den;  // raw_d / den^2 = out_d / den
-        vo[p][D] = vd / den;
-      }
-      float bgdot = 0.f;
-      if (a.background) {
-#pragma unroll
-        for (int c = 0; c < D; c++) bgdot += a.background[c] * vo[p][c];
-      }
-      va[p] = Tfin[p] * (v_al - bgdot);  // both terms carry T_final * ra
-      hi = max(hi, last[p]);
-    }
-    T[p] = Tfin[p];
-  }
-  hi = min(wave_max_i(hi), end - 1);
-  const size_t inst_base = (size_t)s * a.N;
-
-  constexpr float LN2 = 0.6931471805599453f;
-  for (int bh = hi; bh >= start; bh -= 64) {
-    __syncthreads();
-    const int idx = bh - lane;
-    int emit = -1;
-    if (idx >= start) {
-      const int gid = a.sorted_gid[idx];
-      emit = a.sorted_emit[idx];
-      const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
-      const float4 q0 = gp[0], q1 = gp[1];
-      sg0[lane] = q0;
-      // conic pre-scaled by log2(e) (exp2 argument) and 1/opacity for the opacity adjoint
-      sg1[lane] = stage_conic(q1.x, q1.y, q1.z, __builtin_amdgcn_rcpf(q0.z));
-      const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
-#pragma unroll
-      for (int v = 0; v < DV; v++) scol[lane * DV + v] = cp[v];
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) sgrad[lane * RP + r] = 0.f;
-    __syncthreads();
-    const int nb = min(64, bh - start + 1);
-    for (int j = 0; j < nb; j++) {
-      const int cur = bh - j;
-      const float4 g0 = sg0[j], g1 = sg1[j];
-      float dx[4], dy[4], ov[4], am[4];
-      bool valid[4];
-      bool any = false;
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        dx[p] = g0.x - pxf[p];
-        dy[p] = g0.y - pyf[p];
-        const float sig2 = splat_sigma2(g1, dx[p], dy[p]);  // sigma*log2e, bit-identical to the forward
-        ov[p] = g0.z * __builtin_amdgcn_exp2f(-sig2);
-        const float alpha = fminf(0.999f, ov[p]);
-        valid[p] = (cur <= last[p]) && (sig2 >= 0.f) && (alpha >= (1.f / 255.f));
-        am[p] = valid[p] ? alpha : 0.f;
-        any = any || valid[p];
-      }
-      if (!__any(any)) continue;
-      float col[NCH];
-#pragma unroll
-      for (int v = 0; v < DV; v++) {
-        const float4 c4 = scol[j * DV + v];
-        if (v * 4 < D) col[v * 4] = c4.x;
-        if (v * 4 + 1 < D) col[v * 4 + 1] = c4.y;
-        if (v * 4 + 2 < D) col[v * 4 + 2] = c4.z;
-        if (v * 4 + 3 < D) col[v * 4 + 3] = c4.w;
-      }
-      if (DEPTH) col[D] = g0.w;
-      // row = [gx, gy, ga, gb, gc, go, gcol...]; branch-free: an invalid pixel has am = 0 -> ra = 1, fac = 0
-      float row[R];
-#pragma unroll
-      for (int r = 0; r < R; r++) row[r] = 0.f;
-      // v_alpha = sum_c vo_c (col_c T - buf_c ra) + ...  with buf_c = running sum of col_c * fac behind this splat.
-      // Only <vo, buf> is ever needed, so keep that scalar (bsum) instead of the NCH-vector: 2 NCH + 3 FMAs per
-      // (splat, pixel) instead of 5 NCH, and NCH fewer live registers per pixel.
-      float ra[4], fac[4], v_alpha[4];
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        ra[p] = __builtin_amdgcn_rcpf(1.f - am[p]);
-        T[p] *= ra[p];
-        fac[p] = am[p] * T[p];
-        float d = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-          d += vo[p][c] * col[c];
-          row[6 + c] += fac[p] * vo[p][c];
-        }
-        v_alpha[p] = T[p] * d + ra[p] * (va[p] - bsum[p]);
-        bsum[p] += fac[p] * d;
-      }
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const bool ok = valid[p] && (ov[p] <= 0.999f);
-        const float vs = ok ? -ov[p] * v_alpha[p] : 0.f;  // dL/dsigma
-        const float vsx = vs * dx[p], vsy = vs * dy[p];
-        row[2] += vsx * dx[p];              // 2 * dL/da
-        row[3] += vsx * dy[p];              // dL/db
-        row[4] += vsy * dy[p];              // 2 * dL/dc
-        row[0] += 2.f * g1.x * vsx + g1.y * vsy;  // log2e * dL/dx   (g1 = (a/2, b, c/2) log2e)
-        row[1] += g1.y * vsx + 2.f * g1.z * vsy;  // log2e * dL/dy
-        row[5] -= vs;                       // opacity * dL/dopacity
-      }
-      row[0] *= LN2, row[1] *= LN2, row[2] *= 0.5f, row[4] *= 0.5f, row[5] *= g1.w;
-      wave_sum_store(row, sgrad + j * RP, lane);
-    }
-    __syncthreads();
-    if (emit >= 0) {
-      float *dst = a.isect_grad + (size_t)emit * R;
-#pragma unroll
-      for (int r = 0; r < R; r++) dst[r] = sgrad[lane * RP + r];
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Variant B (default): one 256-lane workgroup per tile = 4 waves, each wave owns an 8x8 QUADRANT (1 pixel / lane),
@@ -229,9 +68,6 @@ __global__ void __launch_bounds__(64) k_raster_bwd(const RasterBwdArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef D4GS_ABL
-#define D4GS_ABL 0  // scripts/ablate.sh builds cost-attribution variants: 1 no wave reduction, 2 no gradient math,
-#endif              // 3 neither, 4 list walk only (results are garbage; timing only)
 template <int D, bool DEPTH>
 __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
 #pragma clang fp contract(off)
@@ -401,10 +237,6 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         m &= m - 1;
         const int cur = bh - j;
         const float4 g0 = sg0[j], g1 = sg1[j];
-#if D4GS_ABL == 4
-        T += g0.x + g1.x + (float)cur;
-        continue;
-#endif
         const float dx = g0.x - pxf, dy = g0.y - pyf;
         const float sig2 = splat_sigma2(g1, dx, dy);
         const float ov = g0.z * __builtin_amdgcn_exp2f(-sig2);
@@ -412,20 +244,6 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         const bool valid = (cur <= last) && (sig2 >= 0.f) && (alpha >= (1.f / 255.f));
         if (!__any(valid)) continue;
         const float am = valid ? alpha : 0.f;
-#if D4GS_ABL == 2 || D4GS_ABL == 3
-        {
-          float arow[RV];
-          T += am;
-#pragma unroll
-          for (int r = 0; r < RV; r++) arow[r] = am + (float)r;
-#if D4GS_ABL == 2
-          wave_sum_store(arow, sgrad, (wvs * NB + j) * RP, lane);
-#else
-          if (lane == 0) sgrad[(wvs * NB + j) * RP] = arow[0] + arow[RV - 1];
-#endif
-          continue;
-        }
-#endif
         const float ra = __builtin_amdgcn_rcpf(1.f - am);
         T *= ra;
         const float fac = am * T;
@@ -458,16 +276,7 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
         row[3] = vsx * dy;
         row[4] = vsy * dy;
         row[5] = vs;
-#if D4GS_ABL == 1
-        {
-          float acc = 0.f;
-#pragma unroll
-          for (int r = 0; r < RV; r++) acc += row[r];
-          if (valid) sgrad[(wvs * NB + j) * RP + (lane & 7)] = acc;
-        }
-#else
         wave_sum_store(row, sgrad, (wvs * NB + j) * RP, lane);
-#endif
         if constexpr (MC > 0) {
           if (++nh == 16) {
             flush(16);
@@ -503,264 +312,10 @@ __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Variant C: variant B's mapping, but the per-splat reductions over the quadrant's 64 pixels run on the MATRIX pipe.
-// Every gradient of a splat is a pixel-sum of one of two per-(pixel, splat) scalars times a per-pixel constant:
-//     vs  = dL/dsigma      ->  moments  S_q[j] = sum_p W[q][p] vs[p][j],  W = {1, x, y, x^2, xy, y^2} (quadrant-relative)
-//     fac = alpha * T      ->  colours  V_c[j] = sum_p vo[c][p] fac[p][j]
-// i.e. two GEMMs with K = 64 pixels, A fixed per wave (W is the same for every wave; vo is the quadrant's image
-// gradient) and B produced during the replay.  Lanes write vs / fac to a transposed LDS tile; every 16 valid splats
-// the wave issues 16 + 16 v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fma chain -> deterministic) and 16 lanes turn
-// the 6 moments into d/dx, d/dy, d/dconic, d/dopacity.  This removes the ~45 % of VALU time variant B spends in
-// cross-lane reductions, and the MFMA pipe runs beside the VALU pipe of the SIMD's other waves.
-// ---------------------------------------------------------------------------------------------------------------
-template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) k_raster_bwd_m(const RasterBwdArgs a) {
-#pragma clang fp contract(off)
-  constexpr int NCH = D + (DEPTH ? 1 : 0);
-  constexpr int DP = (D + 3) & ~3;
-  constexpr int DV = DP / 4;
-  constexpr int R = 6 + NCH;
-  constexpr int RP = (R + 1) | 1;
-  constexpr int NB = 64;              // splats per batch
-  constexpr int HF = 8;               // valid splats per MFMA flush (half of the 16 columns of a 16x16x4 tile: LDS budget)
-  constexpr int TS = 66;              // transposed-tile row stride (floats): conflict-free B-fragment reads
-  constexpr int CB = (NCH + 15) / 16; // 16-row colour blocks
-  constexpr float LN2 = 0.6931471805599453f;
-  __shared__ float4 sg0[NB];
-  __shared__ float4 sg1[NB];
-  __shared__ float4 sbox[NB];
-  __shared__ float4 scol[NB * DV];
-  __shared__ float sgrad[4 * NB * RP];
-  constexpr int STRN = (4 * 2 * HF * TS > 256 * NCH) ? 4 * 2 * HF * TS : 256 * NCH;
-  __shared__ float strn[STRN];              // per wave: vsT[HF][TS], facT[HF][TS]; first used to pass the tile's image
-  float *svo = strn;                        // gradient between lanes (A-operand source) before the replay starts
-  __shared__ int shit[4 * HF];
-  __shared__ int shi[4];
+#ifdef D4GS_VARIANTS
+#include "variants/raster_bwd_variants.inc"
+#endif
 
-  if (lists_overflowed(a.n_dev, a.cap, a.max_hint)) return;
-  const int n_tiles_s = a.tw * a.th;
-  const int n_tiles = a.S * n_tiles_s;
-  const int t = xcd_remap_b(blockIdx.x, n_tiles);
-  if (t >= n_tiles) return;
-  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
-  if (end <= start) return;
-  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
-  const int ty = tl / a.tw, tx = tl - ty * a.tw;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int qx0 = tx * D4GS_TILE + (wv & 1) * 8, qy0 = ty * D4GS_TILE + (wv >> 1) * 8;
-  const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
-  const bool inside = x < a.width && y < a.height;
-  const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
-  const float qlx = (float)qx0 + 0.5f, qhx = (float)qx0 + 7.5f, qly = (float)qy0 + 0.5f, qhy = (float)qy0 + 7.5f;
-  const float qcx = (float)qx0 + 4.f, qcy = (float)qy0 + 4.f;  // quadrant centre (pixel-centre coordinates)
-
-  float T = 1.f, va = 0.f, vo[NCH], bsum = 0.f;
-  int last = -1;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) vo[c] = 0.f;
-  if (inside) {
-    const size_t pix = ((size_t)s * a.height + y) * a.width + x;
-    last = a.last_ids[pix];
-    const float al = a.alphas[pix];
-    const float Tfin = a.final_T[pix];
-    const float *vp = a.v_out + pix * NCH;
-#pragma unroll
-    for (int c = 0; c < NCH; c++) vo[c] = vp[c];
-    float v_al = a.v_alphas ? a.v_alphas[pix] : 0.f;
-    if (DEPTH && a.ed) {
-      const float den = fmaxf(al, 1e-10f);
-      const float vd = vo[D];
-      if (al >= 1e-10f) v_al -= vd * a.out[pix * NCH + D] / den;
-      vo[D] = vd / den;
-    }
-    float bgdot = 0.f;
-    if (a.background) {
-#pragma unroll
-      for (int c = 0; c < D; c++) bgdot += a.background[c] * vo[c];
-    }
-    va = Tfin * (v_al - bgdot);
-    T = Tfin;
-  }
-#pragma unroll
-  for (int c = 0; c < NCH; c++) svo[tid * NCH + c] = vo[c];
-  int whi = last < start ? start - 1 : last;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) whi = max(whi, __shfl_xor(whi, o));
-  whi = min(whi, end - 1);
-  if (lane == 0) shi[wv] = whi;
-  __syncthreads();
-  const int hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
-
-  // A fragments (v_mfma_f32_16x16x4_f32: lane l holds A[row = l & 15][k = l >> 4]); k-step kk covers pixels 4kk..4kk+3
-  float a1[16], a2[CB][16];
-  {
-    const int row = lane & 15;
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-      const int p = 4 * kk + (lane >> 4);
-      const float xr = (float)(p & 7) - 3.5f, yr = (float)(p >> 3) - 3.5f;
-      a1[kk] = row == 0 ? 1.f : row == 1 ? xr : row == 2 ? yr : row == 3 ? xr * xr : row == 4 ? xr * yr : row == 5 ? yr * yr : 0.f;
-#pragma unroll
-      for (int cb = 0; cb < CB; cb++) {
-        const int ch = cb * 16 + row;
-        a2[cb][kk] = ch < NCH ? svo[(wv * 64 + p) * NCH + ch] : 0.f;
-      }
-    }
-  }
-  const size_t inst_base = (size_t)s * a.N;
-  float *myslab = sgrad + wv * NB * RP;
-  float *vsT = strn + wv * 2 * HF * TS, *facT = vsT + HF * TS;
-  int *myhit = shit + wv * HF;
-  for (int idx = hi + 1 + tid; idx < end; idx += 256) {
-    float *dst = a.isect_grad + (size_t)a.sorted_emit[idx] * R;
-#pragma unroll
-    for (int r = 0; r < R; r++) dst[r] = 0.f;
-  }
-
-  // turn the accumulated tile (nh valid splats) into gradient rows in this wave's slab
-  auto flush = [&](int nh) {
-    // two accumulators per chain (even / odd k-steps): the dependent-accumulator latency (40 cyc) exceeds the issue
-    // interval (32 cyc); the halves are added in fixed order afterwards
-    f32x4 accm = {0.f, 0.f, 0.f, 0.f}, accm1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 accc[CB], accc1[CB];
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++) accc[cb] = f32x4{0.f, 0.f, 0.f, 0.f}, accc1[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int boff = (lane & 15) < HF ? (lane & 15) * TS + (lane >> 4) : (lane >> 4);  // columns >= HF: any finite data
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 2) {
-      const float bv = vsT[boff + 4 * kk], bf = facT[boff + 4 * kk];
-      const float bv1 = vsT[boff + 4 * kk + 4], bf1 = facT[boff + 4 * kk + 4];
-      accm = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kk], bv, accm, 0, 0, 0);
-      accm1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kk + 1], bv1, accm1, 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < CB; cb++) {
-        accc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[cb][kk], bf, accc[cb], 0, 0, 0);
-        accc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[cb][kk + 1], bf1, accc1[cb], 0, 0, 0);
-      }
-    }
-    accm += accm1;
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++) accc[cb] += accc1[cb];
-    // C/D layout: col (valid splat n) = lane & 15, row = (lane >> 4) * 4 + reg.  Park the tile in LDS (vsT is free now)
-    float *scr = vsT;  // [HF][24 + ...]: moments 0..5, then colours
-    constexpr int SW = 8 + 16 * CB;
-    const int n = lane & 15, r0 = (lane >> 4) * 4;
-    if (n < HF) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (r0 + i < 6) scr[n * SW + r0 + i] = accm[i];
-#pragma unroll
-        for (int cb = 0; cb < CB; cb++)
-          if (cb * 16 + r0 + i < NCH) scr[n * SW + 8 + cb * 16 + r0 + i] = accc[cb][i];
-      }
-    }
-    if (lane < nh) {
-      const int j = myhit[lane];
-      const float4 g0 = sg0[j], g1 = sg1[j];
-      const float *m = scr + lane * SW;
-      const float S0 = m[0], Sx = m[1], Sy = m[2], Sxx = m[3], Sxy = m[4], Syy = m[5];
-      const float mx = g0.x - qcx, my = g0.y - qcy;
-      const float Dx = mx * S0 - Sx, Dy = my * S0 - Sy;
-      const float Dxx = mx * (mx * S0 - 2.f * Sx) + Sxx;
-      const float Dxy = mx * (my * S0 - Sy) - my * Sx + Sxy;
-      const float Dyy = my * (my * S0 - 2.f * Sy) + Syy;
-      float *dst = myslab + j * RP;
-      dst[0] = (2.f * g1.x * Dx + g1.y * Dy) * LN2;
-      dst[1] = (g1.y * Dx + 2.f * g1.z * Dy) * LN2;
-      dst[2] = 0.5f * Dxx;
-      dst[3] = Dxy;
-      dst[4] = 0.5f * Dyy;
-      dst[5] = -S0 * g1.w;
-#pragma unroll
-      for (int c = 0; c < NCH; c++) dst[6 + c] = m[8 + c];
-    }
-  };
-
-  for (int bh = hi; bh >= start; bh -= NB) {
-    __syncthreads();
-    int emit = -1;
-    if (tid < NB) {
-      const int idx = bh - tid;
-      if (idx >= start) {
-        const int gid = a.sorted_gid[idx];
-        emit = a.sorted_emit[idx];
-        const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
-        const float4 q0 = gp[0], q1 = gp[1];
-        sg0[tid] = q0;
-        sg1[tid] = stage_conic(q1.x, q1.y, q1.z, __builtin_amdgcn_rcpf(q0.z));
-        const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
-        const float det = q1.x * q1.z - q1.y * q1.y;
-        const float idet = 1.f / det;
-        float ex = -1.f, ey = -1.f;
-        if (tau > 0.f && det > 0.f) {
-          ex = sqrtf(2.f * tau * q1.z * idet) + 1e-3f;
-          ey = sqrtf(2.f * tau * q1.x * idet) + 1e-3f;
-        }
-        sbox[tid] = ex < 0.f ? make_float4(1e30f, -1e30f, 1e30f, -1e30f)
-                             : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
-        const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
-#pragma unroll
-        for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
-      }
-    }
-    for (int z = tid; z < 4 * NB * RP; z += 256) sgrad[z] = 0.f;
-    __syncthreads();
-    const int nb = min(NB, bh - start + 1);
-    bool hit = false;
-    if (lane < nb && bh - lane <= whi) {
-      const float4 bx = sbox[lane];
-      hit = (bx.x <= qhx) && (bx.y >= qlx) && (bx.z <= qhy) && (bx.w >= qly);
-    }
-    unsigned long long msk = __ballot(hit);
-    int nh = 0;
-    while (msk) {
-      const int j = __ffsll((long long)msk) - 1;
-      msk &= msk - 1;
-      const int cur = bh - j;
-      const float4 g0 = sg0[j], g1 = sg1[j];
-      const float dx = g0.x - pxf, dy = g0.y - pyf;
-      const float sig2 = splat_sigma2(g1, dx, dy);
-      const float ov = g0.z * __builtin_amdgcn_exp2f(-sig2);
-      const float alpha = fminf(0.999f, ov);
-      const bool valid = (cur <= last) && (sig2 >= 0.f) && (alpha >= (1.f / 255.f));
-      if (!__any(valid)) continue;
-      const float am = valid ? alpha : 0.f;
-      const float ra = __builtin_amdgcn_rcpf(1.f - am);
-      T *= ra;
-      const float fac = am * T;
-      float d = 0.f;
-#pragma unroll
-      for (int v = 0; v < DV; v++) {
-        const float4 c4 = scol[j * DV + v];
-        if (v * 4 < D) d = __builtin_fmaf(vo[v * 4], c4.x, d);
-        if (v * 4 + 1 < D) d = __builtin_fmaf(vo[v * 4 + 1], c4.y, d);
-        if (v * 4 + 2 < D) d = __builtin_fmaf(vo[v * 4 + 2], c4.z, d);
-        if (v * 4 + 3 < D) d = __builtin_fmaf(vo[v * 4 + 3], c4.w, d);
-      }
-      if (DEPTH) d = __builtin_fmaf(vo[D], g0.w, d);
-      const float v_alpha = __builtin_fmaf(T, d, ra * (va - bsum));
-      bsum = __builtin_fmaf(fac, d, bsum);
-      const bool ok = valid && (ov <= 0.999f);
-      const float vs = ok ? -ov * v_alpha : 0.f;
-      vsT[nh * TS + lane] = vs;
-      facT[nh * TS + lane] = fac;
-      if (lane == 0) myhit[nh] = j;
-      if (++nh == HF) {
-        flush(HF);
-        nh = 0;
-      }
-    }
-    if (nh) flush(nh);
-    __syncthreads();
-    if (emit >= 0) {
-      float *dst = a.isect_grad + (size_t)emit * R;
-#pragma unroll
-      for (int r = 0; r < R; r++)
-        dst[r] = (sgrad[tid * RP + r] + sgrad[(NB + tid) * RP + r]) + (sgrad[(2 * NB + tid) * RP + r] + sgrad[(3 * NB + tid) * RP + r]);
-    }
-  }
-}
 
 // one lane per Gaussian, looping over sub-samples: sums the contiguous per-intersection rows of each instance
 struct GatherArgs {
@@ -812,13 +367,14 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   if (stats && in) st_acc = a.stats_acc[g], st_vis = a.stats_vis[g], st_mr = a.stats_mr[g];
   // the (count, offset) pair of the next sub-sample is fetched while the current one is streamed and summed
   const size_t gi = in ? g : a.N - 1;
-  int cnt_n = (in && !overflow) ? a.tiles_touched[gi] : 0, off_n = a.isect_offsets[gi];
+  // (an overflowed render never wrote isect_offsets - k_emit returned early: do not read it, stream nothing)
+  int cnt_n = (in && !overflow) ? a.tiles_touched[gi] : 0, off_n = overflow ? 0 : a.isect_offsets[gi];
   for (int s = 0; s < a.S; s++) {
     const size_t i = (size_t)s * a.N + gi;
     const int cnt = cnt_n, off = off_n;
     if (s + 1 < a.S) {
       cnt_n = (in && !overflow) ? a.tiles_touched[i + a.N] : 0;
-      off_n = a.isect_offsets[i + a.N];
+      off_n = overflow ? 0 : a.isect_offsets[i + a.N];
     }
     // span of the wave: [first lane's offset, last lane's offset + count)
     const int base = __builtin_amdgcn_readfirstlane(off);
@@ -922,48 +478,51 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
 
 // Sparse rows pay when most rows are dead, which goes with large footprints: the rows per (sub-sample, Gaussian) instance
 // the lists were sized for is what the host knows without a round trip.  Measured: 1.8 rows per
-// instance -> dense is 3 % faster; 7.4 -> sparse is 13 % faster.  D4GS_BWD_ROWS=dense|sparse overrides.
-static bool choose_sparse(int64_t n_isect, int64_t n_inst) {
-  const char *force = getenv("D4GS_BWD_ROWS");  // read per launch: tests switch it inside one process
-  if (force && force[0] == 'd') return false;
-  if (force && force[0] == 's') return true;
+// instance -> dense is 3 % faster; 7.4 -> sparse is 13 % faster.  D4gsRasterGrads.row_mode overrides.
+static bool choose_sparse(int row_mode, int64_t n_isect, int64_t n_inst) {
+  if (row_mode == D4GS_ROWS_DENSE) return false;
+  if (row_mode == D4GS_ROWS_SPARSE) return true;
   return n_isect >= 6 * (n_inst > 0 ? n_inst : 1);
 }
 
 template <int D, bool DEPTH>
-int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, hipStream_t stream) {
-  constexpr int R = 6 + D + (DEPTH ? 1 : 0);
-  static const bool wave_per_tile = getenv("D4GS_BWD_WAVE_PER_TILE") != nullptr;  // variant A, kept for A/B tests
-  a.sparse = ga.sparse = (!wave_per_tile && getenv("D4GS_BWD_MFMA") == nullptr && choose_sparse(n_isect, (int64_t)a.S * a.N)) ? 1 : 0;
-  if (wave_per_tile) {  // variant A relies on a zeroed buffer; variant B zero-fills what it does not replay itself
-    hipError_t e = hipMemsetAsync(a.isect_grad, 0, sizeof(float) * (size_t)R * (size_t)(n_isect > 0 ? n_isect : 1), stream);
-    if (e != hipSuccess) {
-      d4gs_set_error("hipMemsetAsync(isect_grad): %s", hipGetErrorString(e));
-      return D4GS_ELAUNCH;
-    }
-  }
-  if (a.sparse) {  // variant B marks the rows it writes
-    hipError_t e = hipMemsetAsync(a.live, 0, (((size_t)(n_isect > 0 ? n_isect : 1)) + 3) & ~(size_t)3, stream);
-    if (e != hipSuccess) {
-      d4gs_set_error("hipMemsetAsync(isect_live): %s", hipGetErrorString(e));
-      return D4GS_ELAUNCH;
-    }
-  }
+int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, hipStream_t stream) {
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
-  if (n_isect > 0) {
-    // variant C (reductions on the matrix pipe) is opt-in: measured on MI355X it is slower than B at 4 channels
-    // (1.04-1.24 vs 0.81 ms on cfg2) and only ~5 % faster at 17 (2.06 vs 2.16 ms) - see DESIGN.md section 4
-    static const bool use_mfma = getenv("D4GS_BWD_MFMA") != nullptr;
-    if (wave_per_tile)
-      D4GS_LAUNCH("k_raster_bwd", (k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
-    else if (use_mfma)
-      D4GS_LAUNCH("k_raster_bwd_m", (k_raster_bwd_m<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
-    else
-      D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
-    int rc = d4gs_check_launch("k_raster_bwd");
-    if (rc) return rc;
+  bool launched = false;
+  a.sparse = ga.sparse = choose_sparse(row_mode, n_isect, (int64_t)a.S * a.N) ? 1 : 0;
+#ifdef D4GS_VARIANTS  // the A/B build only (tests/libd4gs_variants.so): environment-selected reference variants, dense rows
+  static const bool wave_per_tile = getenv("D4GS_BWD_WAVE_PER_TILE") != nullptr;  // variant A
+  static const bool use_mfma = getenv("D4GS_BWD_MFMA") != nullptr;                // variant C
+  if (wave_per_tile || use_mfma) {
+    constexpr int R = 6 + D + (DEPTH ? 1 : 0);
+    a.sparse = ga.sparse = 0;
+    if (wave_per_tile) {  // variant A relies on a zeroed buffer
+      hipError_t e = hipMemsetAsync(a.isect_grad, 0, sizeof(float) * (size_t)R * (size_t)(n_isect > 0 ? n_isect : 1), stream);
+      if (e != hipSuccess) {
+        d4gs_set_error("hipMemsetAsync(isect_grad): %s", hipGetErrorString(e));
+        return D4GS_ELAUNCH;
+      }
+    }
+    if (n_isect > 0) {
+      if (wave_per_tile) D4GS_LAUNCH("k_raster_bwd", (k_raster_bwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
+      else D4GS_LAUNCH("k_raster_bwd_m", (k_raster_bwd_m<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+    }
+    launched = true;
   }
+#endif
+  if (!launched) {
+    if (a.sparse) {  // the composite marks the rows it writes
+      hipError_t e = hipMemsetAsync(a.live, 0, (((size_t)(n_isect > 0 ? n_isect : 1)) + 3) & ~(size_t)3, stream);
+      if (e != hipSuccess) {
+        d4gs_set_error("hipMemsetAsync(isect_live): %s", hipGetErrorString(e));
+        return D4GS_ELAUNCH;
+      }
+    }
+    if (n_isect > 0) D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+  }
+  int rc = d4gs_check_launch("k_raster_bwd");
+  if (rc) return rc;
   if (ga.sparse)
     D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH, true>), dim3((ga.N + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, stream, ga);
   else
@@ -1003,7 +562,7 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
 #define D4GS_CASE(DD)                                                                             \
   case DD:                                                                                        \
-    return dep ? launch_bwd<DD, true>(a, ga, isect->n_isect, stream) : launch_bwd<DD, false>(a, ga, isect->n_isect, stream);
+    return dep ? launch_bwd<DD, true>(a, ga, isect->n_isect, g->row_mode, stream) : launch_bwd<DD, false>(a, ga, isect->n_isect, g->row_mode, stream);
   switch (dims->D) {
     D4GS_CASE(1)
     D4GS_CASE(2)

@@ -38,234 +38,9 @@ __device__ __forceinline__ int xcd_remap(int b, int n_blocks) {
   return (b & 7) * per + (b >> 3);
 }
 
-template <int D, bool DEPTH>
-__global__ void __launch_bounds__(64) k_raster_fwd(const RasterFwdArgs a) {
-#pragma clang fp contract(off)
-  constexpr int NCH = D + (DEPTH ? 1 : 0);
-  constexpr int DP = (D + 3) & ~3;
-  constexpr int DV = DP / 4;
-  __shared__ float4 sg0[64];
-  __shared__ float4 sg1[64];
-  __shared__ float4 scol[64 * DV];
-
-  if (a.n_dev && (a.n_dev[0] > a.cap || (a.max_hint > 0 && a.n_dev[1] > a.max_hint))) return;
-  const int n_tiles_s = a.tw * a.th;
-  const int n_tiles = a.S * n_tiles_s;
-  const int t = xcd_remap(blockIdx.x, n_tiles);
-  if (t >= n_tiles) return;
-  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
-  const int ty = tl / a.tw, tx = tl - ty * a.tw;
-  const int lane = threadIdx.x;
-  const int x0 = tx * D4GS_TILE + 2 * (lane & 7), y0 = ty * D4GS_TILE + 2 * (lane >> 3);
-
-  float pxf[4], pyf[4], T[4], acc[4][NCH];
-  int last[4];
-  bool done[4];
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
-    const int x = x0 + (p & 1), y = y0 + (p >> 1);
-    pxf[p] = (float)x + 0.5f;
-    pyf[p] = (float)y + 0.5f;
-    T[p] = 1.f;
-    last[p] = 0;
-    done[p] = !(x < a.width && y < a.height);
-#pragma unroll
-    for (int c = 0; c < NCH; c++) acc[p][c] = 0.f;
-  }
-
-  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
-  const size_t inst_base = (size_t)s * a.N;
-  for (int b = start; b < end; b += 64) {
-    if (__all(done[0] && done[1] && done[2] && done[3])) break;
-    __syncthreads();
-    const int idx = b + lane;
-    if (idx < end) {
-      const int gid = a.sorted_gid[idx];
-      const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
-      const float4 q1 = gp[1];
-      sg0[lane] = gp[0];
-      sg1[lane] = stage_conic(q1.x, q1.y, q1.z, 0.f);  // exp2 argument (same as the bwd)
-      const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
-#pragma unroll
-      for (int v = 0; v < DV; v++) scol[lane * DV + v] = cp[v];
-    }
-    __syncthreads();
-    const int nb = min(64, end - b);
-    for (int j = 0; j < nb; j++) {
-      if ((j & 15) == 0 && j && __all(done[0] && done[1] && done[2] && done[3])) break;
-      const float4 g0 = sg0[j], g1 = sg1[j];
-      float col[DP];
-#pragma unroll
-      for (int v = 0; v < DV; v++) {
-        const float4 c4 = scol[j * DV + v];
-        col[v * 4] = c4.x, col[v * 4 + 1] = c4.y, col[v * 4 + 2] = c4.z, col[v * 4 + 3] = c4.w;
-      }
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const float dx = g0.x - pxf[p], dy = g0.y - pyf[p];
-        const float sigma = splat_sigma2(g1, dx, dy);  // sigma * log2(e)
-        const float alpha = fminf(0.999f, g0.z * __builtin_amdgcn_exp2f(-sigma));
-        bool valid = !done[p] && (sigma >= 0.f) && (alpha >= (1.f / 255.f));
-        const float nT = T[p] * (1.f - alpha);
-        const bool stop = valid && (nT <= 1e-4f);
-        done[p] = done[p] || stop;
-        valid = valid && !stop;
-        const float vis = valid ? alpha * T[p] : 0.f;
-#pragma unroll
-        for (int c = 0; c < D; c++) acc[p][c] = __builtin_fmaf(col[c], vis, acc[p][c]);
-        if (DEPTH) acc[p][D] = __builtin_fmaf(g0.w, vis, acc[p][D]);
-        T[p] = valid ? nT : T[p];
-        last[p] = valid ? (b + j) : last[p];
-      }
-    }
-  }
-
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
-    const int x = x0 + (p & 1), y = y0 + (p >> 1);
-    if (x < a.width && y < a.height) {
-      const size_t pix = ((size_t)s * a.height + y) * a.width + x;
-      const float al = 1.f - T[p];
-      a.alphas[pix] = al;
-      a.final_T[pix] = T[p];
-      a.last_ids[pix] = last[p];
-      float *o = a.out + pix * NCH;
-#pragma unroll
-      for (int c = 0; c < D; c++) o[c] = acc[p][c] + (a.background ? T[p] * a.background[c] : 0.f);
-      if (DEPTH) o[D] = a.ed ? acc[p][D] / fmaxf(al, 1e-10f) : acc[p][D];
-    }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Variant B (default): one 256-lane workgroup per tile = 4 waves, each wave owns an 8x8 QUADRANT (1 pixel / lane).
-// Batches of 256 splats are staged once per tile; at staging every lane also computes its splat's tight
-// alpha >= 1/255 bounding box (same margins as D4GS_EXACT_CULL).  Each wave then ballots "does splat j touch MY
-// quadrant" (4 x 64-bit masks per batch) and walks only the set bits, so a splat that covers one corner of the tile
-// costs one wave ~30 instructions instead of the whole tile 126.  Arithmetic per (splat, pixel) is identical to
-// variant A, and skipped pairs would have failed the alpha test: the two variants are bitwise identical.
-// ---------------------------------------------------------------------------------------------------------------
-template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) k_raster_fwd_q(const RasterFwdArgs a) {
-#pragma clang fp contract(off)
-  constexpr int NCH = D + (DEPTH ? 1 : 0);
-  constexpr int DP = (D + 3) & ~3;
-  constexpr int DV = DP / 4;
-  constexpr int FB = 256;  // splats per batch (forward)
-  __shared__ float4 sg0[FB];
-  __shared__ float4 sg1[FB];
-  __shared__ float4 sbox[FB];
-  __shared__ float4 scol[FB * DV];
-
-  if (a.n_dev && (a.n_dev[0] > a.cap || (a.max_hint > 0 && a.n_dev[1] > a.max_hint))) return;
-  const int n_tiles_s = a.tw * a.th;
-  const int n_tiles = a.S * n_tiles_s;
-  const int t = xcd_remap(blockIdx.x, n_tiles);
-  if (t >= n_tiles) return;
-  const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
-  const int ty = tl / a.tw, tx = tl - ty * a.tw;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int qx0 = tx * D4GS_TILE + (wv & 1) * 8, qy0 = ty * D4GS_TILE + (wv >> 1) * 8;
-  const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
-  const bool inside = x < a.width && y < a.height;
-  const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
-  // pixel-centre extent of this wave's quadrant
-  const float qlx = (float)qx0 + 0.5f, qhx = (float)qx0 + 7.5f, qly = (float)qy0 + 0.5f, qhy = (float)qy0 + 7.5f;
-
-  float T = 1.f, acc[NCH];
-  int last = 0;
-  bool done = !inside;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) acc[c] = 0.f;
-
-  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
-  const size_t inst_base = (size_t)s * a.N;
-  for (int b = start; b < end; b += FB) {
-    if (__syncthreads_and(done)) break;  // also orders the previous batch's LDS reads before restaging
-    const int idx = b + tid;
-    if (tid < FB && idx < end) {
-      const int gid = a.sorted_gid[idx];
-      const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
-      const float4 q0 = gp[0], q1 = gp[1];
-      sg0[tid] = q0;
-      sg1[tid] = stage_conic(q1.x, q1.y, q1.z, 0.f);
-      // tight box: sigma <= tau, tau = ln(255 opacity) (+ margins); Sigma = conic^-1
-      const float tau = __logf(255.f * q0.z) * 1.01f + 0.02f;
-      const float det = q1.x * q1.z - q1.y * q1.y;
-      const float idet = 1.f / det;
-      float ex = -1.f, ey = -1.f;
-      if (tau > 0.f && det > 0.f) {
-        ex = sqrtf(2.f * tau * q1.z * idet) + 1e-3f;
-        ey = sqrtf(2.f * tau * q1.x * idet) + 1e-3f;
-      }
-      sbox[tid] = ex < 0.f ? make_float4(1e30f, -1e30f, 1e30f, -1e30f) : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
-      const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
-#pragma unroll
-      for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
-    }
-    __syncthreads();
-    const int nb = min(FB, end - b);
-    unsigned long long mask[FB / 64];
-#pragma unroll
-    for (int k = 0; k < FB / 64; k++) {
-      const int j = k * 64 + lane;
-      bool hit = false;
-      if (j < nb) {
-        const float4 bx = sbox[j];
-        hit = (bx.x <= qhx) && (bx.y >= qlx) && (bx.z <= qhy) && (bx.w >= qly);
-      }
-      mask[k] = __ballot(hit);
-    }
-    bool wdone = false;
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < FB / 64; k++) {
-      unsigned long long m = wdone ? 0ull : mask[k];
-      while (m) {
-        const int j = k * 64 + (__ffsll((long long)m) - 1);
-        m &= m - 1;
-        const float4 g0 = sg0[j], g1 = sg1[j];
-        const float dx = g0.x - pxf, dy = g0.y - pyf;
-        const float sigma = splat_sigma2(g1, dx, dy);  // sigma * log2(e)
-        const float alpha = fminf(0.999f, g0.z * __builtin_amdgcn_exp2f(-sigma));
-        bool valid = !done && (sigma >= 0.f) && (alpha >= (1.f / 255.f));
-        const float nT = T * (1.f - alpha);
-        const bool stop = valid && (nT <= 1e-4f);
-        done = done || stop;
-        valid = valid && !stop;
-        const float vis = valid ? alpha * T : 0.f;
-#pragma unroll
-        for (int v = 0; v < DV; v++) {
-          const float4 c4 = scol[j * DV + v];
-          if (v * 4 < D) acc[v * 4] = __builtin_fmaf(c4.x, vis, acc[v * 4]);
-          if (v * 4 + 1 < D) acc[v * 4 + 1] = __builtin_fmaf(c4.y, vis, acc[v * 4 + 1]);
-          if (v * 4 + 2 < D) acc[v * 4 + 2] = __builtin_fmaf(c4.z, vis, acc[v * 4 + 2]);
-          if (v * 4 + 3 < D) acc[v * 4 + 3] = __builtin_fmaf(c4.w, vis, acc[v * 4 + 3]);
-        }
-        if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
-        T = valid ? nT : T;
-        last = valid ? (b + j) : last;
-        if ((++cnt & 15) == 0 && __all(done)) {
-          m = 0;
-          wdone = true;
-        }
-      }
-    }
-  }
-
-  if (inside) {
-    const size_t pix = ((size_t)s * a.height + y) * a.width + x;
-    const float al = 1.f - T;
-    a.alphas[pix] = al;
-    a.final_T[pix] = T;
-    a.last_ids[pix] = last;
-    float *o = a.out + pix * NCH;
-#pragma unroll
-    for (int c = 0; c < D; c++) o[c] = acc[c] + (a.background ? T * a.background[c] : 0.f);
-    if (DEPTH) o[D] = a.ed ? acc[D] / fmaxf(al, 1e-10f) : acc[D];
-  }
-}
+#ifdef D4GS_VARIANTS
+#include "variants/raster_fwd_variants.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Variant D: variant B's tile / quadrant mapping, but the four 16-lane ROWS of a quadrant-wave are four independent
@@ -416,15 +191,20 @@ template <int D, bool DEPTH>
 int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
-  static const bool wave_per_tile = getenv("D4GS_FWD_WAVE_PER_TILE") != nullptr;  // variant A, kept for A/B tests
-  static const bool quads = getenv("D4GS_FWD_QUADS") != nullptr;  // variant B
-  if (wave_per_tile)
+#ifdef D4GS_VARIANTS  // the A/B build only (tests/libd4gs_variants.so): environment-selected reference variants
+  static const bool wave_per_tile = getenv("D4GS_FWD_WAVE_PER_TILE") != nullptr;  // variant A
+  static const bool quads = getenv("D4GS_FWD_QUADS") != nullptr;                  // variant B
+  if (wave_per_tile) {
     D4GS_LAUNCH("k_raster_fwd", (k_raster_fwd<D, DEPTH>), dim3(blocks), dim3(64), 0, stream, a);
-  else if (!quads)
-    D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
-  else
+    return d4gs_check_launch("k_raster_fwd");
+  }
+  if (quads) {
     D4GS_LAUNCH("k_raster_fwd_q", (k_raster_fwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
-  return d4gs_check_launch("k_raster_fwd");
+    return d4gs_check_launch("k_raster_fwd_q");
+  }
+#endif
+  D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+  return d4gs_check_launch("k_raster_fwd_r");
 }
 
 }  // namespace

@@ -86,6 +86,9 @@ class State:
     binned: bool = False
 
 
+BWD_ROWS = "auto"  # "auto" | "dense" | "sparse": gradient-row mode of the composite backward (D4gsRasterGrads.row_mode);
+#                    "auto" lets the library choose from the list capacity per instance.  Module-level so tests can force it.
+
 SUPPORTED_D = (1, 2, 3, 4, 5, 8, 16)  # colour-channel instantiations of the composite kernels (+ optional depth)
 
 
@@ -148,41 +151,59 @@ def _guess_put(key, val):
             _SIZE_GUESS.popitem(last=False)
 
 
-_DEFERRED: dict = {}  # size key -> (pinned int64[2], event, capacity, max-tile hint) of the last unchecked render
+_DEFERRED: dict = {}  # size key -> [(pinned int64[2], event, capacity, max-tile hint), ...]: EVERY unchecked render of that
+#                       shape, oldest first (a training step issues several renders of one shape before any count lands)
 
 
 _PINNED_FREE: list = []  # pinned int64[2] buffers whose deferred count has been consumed (guarded by _SIZE_LOCK)
 
 
 def _deferred_poll(key, block: bool = False):
-    """Look at the count of the previous deferred render of this shape, if it has arrived.  -> (n, max_tile) | None."""
+    """Look at the counts of the earlier deferred renders of this shape that have arrived (all of them when `block`).
+    Every record is verified - none is dropped when the host runs ahead of the device; an overflow raises after the
+    whole batch has been read and the size guess updated.  -> (n, max_tile) of the newest record read | None."""
     with _SIZE_LOCK:
-        rec = _DEFERRED.get(key)
-    if rec is None:
-        return None
-    host_n, ev, cap, hint = rec
-    if not block and not ev.query():
-        return None
-    ev.synchronize()
-    with _SIZE_LOCK:
-        _DEFERRED.pop(key, None)
-    n, max_tile = host_n.tolist()
-    with _SIZE_LOCK:  # the copy has landed and been read: the pinned pair can carry the next count
-        if len(_PINNED_FREE) < 64:
-            _PINNED_FREE.append(host_n)
-    _guess_put(key, (n + n // 4 + 4096, _sort_class(max_tile)))
-    if n > cap or (hint > 0 and max_tile > hint):
+        recs = _DEFERRED.get(key)
+        if not recs:
+            return None
+        ready = []
+        while recs and (block or recs[0][1].query()):  # stream order: an older copy lands before a newer one
+            ready.append(recs.pop(0))
+        if not recs:
+            _DEFERRED.pop(key, None)
+    last, bad = None, None
+    for host_n, ev, cap, hint in ready:
+        ev.synchronize()
+        n, max_tile = host_n.tolist()
+        with _SIZE_LOCK:  # the copy has landed and been read: the pinned pair can carry the next count
+            if len(_PINNED_FREE) < 64:
+                _PINNED_FREE.append(host_n)
+        last = (n, max_tile)
+        if (n > cap or (hint > 0 and max_tile > hint)) and bad is None:
+            bad = (n, max_tile, cap, hint)
+    if last is not None:
+        _guess_put(key, (last[0] + last[0] // 4 + 4096, _sort_class(last[1])))
+    if bad is not None:
+        if bad[0] + bad[0] // 4 + 4096 > (last[0] + last[0] // 4 + 4096):
+            _guess_put(key, (bad[0] + bad[0] // 4 + 4096, _sort_class(max(bad[1], last[1]))))
+        n, max_tile, cap, hint = bad
         raise RuntimeError(f"deblur4dgs_amd: a render with deferred_size_check needed {n} intersections (longest tile "
                            f"list {max_tile}) but its lists were sized for {cap} (class {hint}): that render's output "
                            "was INVALID (its kernels skipped the work).  Re-run the step; the size guess is updated.")
-    return n, max_tile
+    return last
 
 
 def check_deferred():
     """Wait for and verify every outstanding deferred size check (call once per training step, e.g. where the loss is
-    read back anyway).  Raises RuntimeError if a render overflowed its intersection lists."""
+    read back anyway).  Raises RuntimeError if any render since the last call overflowed its intersection lists."""
+    err = None
     for key in list(_DEFERRED):
-        _deferred_poll(key, block=True)
+        try:
+            _deferred_poll(key, block=True)
+        except RuntimeError as e:  # keep draining the other shapes: their records must not outlive this call
+            err = err or e
+    if err is not None:
+        raise err
 
 
 def _pinned_counts(dev):
@@ -375,7 +396,7 @@ class RasterFn(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record()
                 with _SIZE_LOCK:
-                    _DEFERRED[key] = (host_n, ev, guess[0], guess[1])
+                    _DEFERRED.setdefault(key, []).append((host_n, ev, guess[0], guess[1]))
             st.n_isect, st.max_tile, st.binned = guess[0], guess[1], True
             st.raster = rst
             _SIZE_STATS["calls"] += 1
@@ -429,6 +450,7 @@ class RasterFn(torch.autograd.Function):
         isect.n_isect, isect.max_tile_count = st.n_isect, st.max_tile
         ras = L.fill(L.Raster(), **rst)
         rg = L.fill(L.RasterGrads(), **g)
+        rg.row_mode = {"auto": L.ROWS_AUTO, "dense": L.ROWS_DENSE, "sparse": L.ROWS_SPARSE}[BWD_ROWS]
         if cfg.control_stats is not None:  # fused statistics: the gather epilogue owns v_means2d and reads radii
             cs = _check_stats(cfg.control_stats, N)
             rg.stats_grad_norm_acc, rg.stats_vis_count = L.ptr(cs["xys_grad_norm_acc"]), L.ptr(cs["vis_count"])
@@ -439,60 +461,90 @@ class RasterFn(torch.autograd.Function):
         return None, None, g["v_means2d"], g["v_conics"], g["v_depths"], g["v_opac_act"], g["v_ctab"], None
 
 
-class PointsFn(torch.autograd.Function):
-    """a11 (flow3d/scene_model.py:258-289): camera-space positions of all N Gaussians at B target times,
-    `points[b,g] = target_w2cs[b,:3] @ [deform(g, target_ts[b]); 1]` -> [B,N,3].  d4gs_points_fwd / d4gs_points_bwd
-    (the deformation half of the projection kernels in "points only" mode)."""
+class PosesFn(torch.autograd.Function):
+    """The pose API of the S2 seam (flow3d/scene_model.py:58-120) and the a11 track channels (:258-289) on the HIP path:
+    d4gs_poses_fwd / d4gs_poses_bwd.  For the B times `ts` -> any of
+      means  [N,B,3]   R_b means + t_b for the first G = len(motion_coefs) rows, the raw means for the static rest (then,
+                       for the track channels, expressed in the cameras `w2cs34 [B,3,4]`),
+      quats  [N,B,4]   wxyz, unit: normalize(rotmat_to_unitquat(R_b) (x) normalize(quats)),
+      tfs    [G,B,3,4] MotionBases.compute_transforms(ts, softmax(motion_coefs)).
+    `g_major` picks the memory layout of the reference's tensors ((G,B,...) contiguous); time-major otherwise."""
 
     @staticmethod
-    def forward(ctx, means, motion_coefs, rots, transls, target_ts, target_w2cs34):
+    def forward(ctx, means, quats, motion_coefs, rots, transls, ts, w2cs34, want: tuple, g_major: bool, raw_coefs: bool = True):
         _need_gpu(means)
         dev = means.device
-        N, B = means.shape[0], target_ts.shape[0]
+        N, B = means.shape[0], ts.shape[0]
         G = 0 if motion_coefs is None else motion_coefs.shape[0]
         K, T = (rots.shape[0], rots.shape[1]) if G > 0 else (0, 0)
-        cfg = RenderCfg(N=N, G=G, K=K, T=T, S=B, D=1, width=16, height=16, flags=L.RAW_PARAMS, exact_cull=False)
-        eye4 = torch.eye(4, device=dev)
-        pin = dict(means=_f32c(means), quats=None, scales=None, opacities=None, colors=None,
-                   motion_coefs=_f32c(motion_coefs), rots=_f32c(rots), transls=_f32c(transls), times=_f32c(target_ts),
-                   RTs=_f32c(target_w2cs34), viewmat=eye4, Kmat=eye4[:3, :3].contiguous())
-        pts = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        want_m, want_q, want_t = want
+        cfg = RenderCfg(N=N, G=G, K=K, T=T, S=B, D=1, width=16, height=16, flags=L.RAW_PARAMS if raw_coefs else 0,
+                        exact_cull=False)
+        pin = dict(means=_f32c(means), quats=_f32c(quats) if want_q else None, scales=None, opacities=None, colors=None,
+                   motion_coefs=_f32c(motion_coefs), rots=_f32c(rots), transls=_f32c(transls), times=_f32c(ts),
+                   RTs=_f32c(w2cs34), viewmat=None, Kmat=None)
+        f32 = dict(dtype=torch.float32, device=dev)
+        shp = (lambda n, *r: (n, B, *r)) if g_major else (lambda n, *r: (B, n, *r))
+        out = dict(means=torch.empty(shp(N, 3), **f32) if want_m else None,
+                   quats=torch.empty(shp(N, 4), **f32) if want_q else None,
+                   transforms=torch.empty(shp(G, 3, 4), **f32) if want_t and G > 0 else None)
+        po = L.fill(L.Poses(), **out)
+        po.g_major = int(g_major)
         dims = cfg.dims()
-        L.check(L.lib().d4gs_points_fwd(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pin)), L.ptr(pts), _stream()),
-                "d4gs_points_fwd")
-        ctx.cfg, ctx.pin = cfg, pin
-        ctx.needs = [t is not None and t.requires_grad for t in (means, motion_coefs, rots, transls, target_ts,
-                                                                 target_w2cs34)]
-        return pts
+        if any(v is not None for v in out.values()):
+            L.check(L.lib().d4gs_poses_fwd(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pin)), C.byref(po), _stream()),
+                    "d4gs_poses_fwd")
+        ctx.cfg, ctx.g_major, ctx.want = cfg, bool(g_major), want
+        ctx.keys = [k for k, v in pin.items() if v is not None]
+        ctx.save_for_backward(*[pin[k] for k in ctx.keys])  # version-checked, like ProjectFn
+        ctx.needs = [t is not None and t.requires_grad for t in (means, quats, motion_coefs, rots, transls, ts, w2cs34)]
+        if want_t and out["transforms"] is None:
+            out["transforms"] = torch.zeros(shp(0, 3, 4), **f32)
+        return out["means"], out["quats"], out["transforms"]
 
     @staticmethod
-    def backward(ctx, v_pts):
-        cfg, pin = ctx.cfg, ctx.pin
-        dev = v_pts.device
+    def backward(ctx, v_means, v_quats, v_tfs):
+        cfg = ctx.cfg
+        pin = dict.fromkeys(_PROJ_IN)
+        pin.update(zip(ctx.keys, ctx.saved_tensors))
+        dev = pin["means"].device
         f32 = dict(dtype=torch.float32, device=dev)
         lib = L.lib()
         dims = cfg.dims()
         dyn = cfg.G > 0
-        g = dict(v_means=torch.empty(cfg.N, 3, **f32), v_quats=None, v_scales=None, v_opacities=None, v_colors=None,
+        c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        if not dyn:
+            v_tfs = None
+        vo = L.fill(L.Poses(), means=c(v_means), quats=c(v_quats) if pin["quats"] is not None else None, transforms=c(v_tfs))
+        vo.g_major = int(ctx.g_major)
+        g = dict(v_means=torch.empty(cfg.N, 3, **f32), v_quats=torch.empty(cfg.N, 4, **f32) if vo.quats else None,
+                 v_scales=None, v_opacities=None, v_colors=None,
                  v_motion_coefs=torch.empty(cfg.G, cfg.K, **f32) if dyn else None,
                  v_rots=torch.empty(cfg.K, cfg.T, 6, **f32) if dyn else None,
                  v_transls=torch.empty(cfg.K, cfg.T, 3, **f32) if dyn else None,
                  v_times=torch.empty(cfg.S, **f32) if dyn else None,
                  v_RTs=torch.empty(cfg.S, 3, 4, **f32) if pin["RTs"] is not None else None,
-                 v_viewmat=torch.empty(4, 4, **f32),
+                 v_viewmat=None,
                  partials=torch.empty(lib.d4gs_bwd_partials_elems(C.byref(dims)), **f32))
-        L.check(lib.d4gs_points_bwd(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pin)),
-                                    L.ptr(v_pts.to(torch.float32).contiguous()), C.byref(L.fill(L.LeafGrads(), **g)),
-                                    _stream()), "d4gs_points_bwd")
-        outs = [g["v_means"], g["v_motion_coefs"], g["v_rots"], g["v_transls"], g["v_times"], g["v_RTs"]]
-        return tuple(x if need else None for x, need in zip(outs, ctx.needs))
+        L.check(lib.d4gs_poses_bwd(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pin)), C.byref(vo),
+                                   C.byref(L.fill(L.LeafGrads(), **g)), _stream()), "d4gs_poses_bwd")
+        outs = [g["v_means"], g["v_quats"], g["v_motion_coefs"], g["v_rots"], g["v_transls"], g["v_times"], g["v_RTs"]]
+        return (*(x if need else None for x, need in zip(outs, ctx.needs)), None, None, None)
+
+
+def poses(means, quats, motion_coefs, rots, transls, ts, want=(True, True, False), raw_coefs=True):
+    """-> (means [N,B,3] | None, quats [N,B,4] | None, transforms [G,B,3,4] | None) in the reference's (G,B,...) layout
+    (flow3d/scene_model.py:58-120); the first G = len(motion_coefs) Gaussians are dynamic.  raw_coefs=False: the
+    coefficients are already activated (MotionBases.compute_transforms' own signature, params.py:142)."""
+    return PosesFn.apply(means, quats, motion_coefs, rots, transls, ts, None, tuple(want), True, raw_coefs)
 
 
 def track_points(means, motion_coefs, rots, transls, target_ts, target_w2cs=None):
     """-> [N,B,3] positions of all Gaussians (the first G = len(motion_coefs) deformed) at `target_ts`, expressed in
     the cameras `target_w2cs [B,4,4]` (world frame if None)."""
     w34 = None if target_w2cs is None else target_w2cs[:, :3, :]
-    return PointsFn.apply(means, motion_coefs, rots, transls, target_ts, w34).permute(1, 0, 2)
+    pts, _, _ = PosesFn.apply(means, None, motion_coefs, rots, transls, target_ts, w34, (True, False, False), False)
+    return pts.permute(1, 0, 2)
 
 
 def render_instances(cfg: RenderCfg, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs,

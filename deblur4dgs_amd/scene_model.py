@@ -118,20 +118,23 @@ class MotionBases(nn.Module):
         return MotionBases(state_dict[f"{prefix}rots"], state_dict[f"{prefix}transls"])
 
     def compute_transforms(self, ts: torch.Tensor, coefs: torch.Tensor) -> torch.Tensor:
-        """(G,B,3,4) transforms at times ts (params.py:142-180).  Only used for the track channels (a11) - the
-        render path deforms inside the HIP kernels."""
-        if ts.dim() == 1:
-            ts = ts[None]
-        T = self.params["transls"].shape[1]
-        f = torch.floor(ts).clamp(0.0, T - 1).int()
-        c = torch.ceil(ts).clamp(0.0, T - 1).int()
-        w = (ts - f)[..., None]
-        blend = lambda x: (1.0 - w) * torch.einsum("pk,kni->pni", coefs, x[:, f[0].long()]) + \
-            w * torch.einsum("pk,kni->pni", coefs, x[:, c[0].long()])
-        tr, r6 = blend(self.params["transls"]), blend(self.params["rots"])
-        x = F.normalize(r6[..., :3], dim=-1)
-        y = F.normalize(r6[..., 3:] - (r6[..., 3:] * x).sum(-1, keepdim=True) * x, dim=-1)
-        return torch.cat([torch.stack([x, y, torch.linalg.cross(x, y, dim=-1)], -1), tr[..., None]], -1)
+        """(G,B,3,4) transforms at times ts (B,) for ACTIVATED coefficients `coefs` (G,K): flow3d/params.py:142-180 on
+        the HIP path (d4gs_poses_fwd/bwd with D4GS_RAW_PARAMS clear: the coefficients are used as given)."""
+        return _transforms(self, ts, coefs, raw=False)
+
+
+def _ts1d(ts: torch.Tensor) -> torch.Tensor:
+    """(B,) float32 times; the reference also accepts (1,B) (params.py:150-151) and integer frame indices."""
+    ts = ts.reshape(-1) if ts.dim() == 2 and ts.shape[0] == 1 else ts
+    assert ts.dim() == 1, "ts must be (B,) or (1,B)"
+    return ts.to(torch.float32)
+
+
+def _transforms(bases: "MotionBases", ts, coefs, raw: bool):
+    from .engine import poses
+
+    return poses(coefs.new_zeros(coefs.shape[0], 3), None, coefs, bases.params["rots"], bases.params["transls"], _ts1d(ts),
+                 want=(False, False, True), raw_coefs=raw)[2]
 
 
 class SceneModel(nn.Module):
@@ -197,15 +200,45 @@ class SceneModel(nn.Module):
         mb = MotionBases.init_from_state_dict(state_dict, prefix=f"{prefix}motion_bases.params.")
         return SceneModel(state_dict[f"{prefix}Ks"], state_dict[f"{prefix}w2cs"], fg, mb, bg)
 
-    # ---- a11: positions at other times (track channels), scene_model.py:58-120 on the MEANS only
-    def compute_means_at(self, ts: torch.Tensor, which: str) -> torch.Tensor:
-        parts = []
-        if which in ("fg", "all"):
-            tf = self.motion_bases.compute_transforms(ts, self.fg.get_coefs())
-            parts.append(torch.einsum("pnij,pj->pni", tf, F.pad(self.fg.params["means"], (0, 1), value=1.0)))
-        if which in ("bg", "all") and self.bg is not None:
-            parts.append(self.bg.params["means"][:, None].expand(-1, ts.shape[-1], -1))
-        return torch.cat(parts, 0)
+    # ---- a4 / a5: the pose API the reference's Trainer / Renderer call on the model (flow3d/trainer.py:303,478,485,701,818;
+    # flow3d/renderer.py:37), reference flow3d/scene_model.py:58-120, on the HIP path (engine.PosesFn) ----
+    def compute_poses_bg(self) -> tuple[torch.Tensor, torch.Tensor]:
+        """-> means (G_bg,3), quats (G_bg,4) (scene_model.py:58-65)."""
+        assert self.bg is not None
+        m, q = self._poses(self.bg.params["means"], self.bg.params["quats"], None, None)
+        return m[:, 0], q[:, 0]
+
+    def compute_transforms(self, ts: torch.Tensor, inds: torch.Tensor | None = None) -> torch.Tensor:
+        """-> (G,B,3,4) (scene_model.py:67-74)."""
+        coefs = self.fg.params["motion_coefs"]
+        if inds is not None:
+            coefs = coefs[inds]  # softmax is row-wise: softmax(c)[inds] == softmax(c[inds])
+        return _transforms(self.motion_bases, ts, coefs, raw=True)
+
+    def _poses(self, means, quats, coefs, ts):
+        """means (n,B,3), quats (n,B,4): the first len(coefs) rows deformed to the times ts; ts None = the canonical
+        pose (B = 1; means as given, quats normalised)."""
+        from .engine import poses
+
+        if ts is None:
+            coefs, ts = None, means.new_zeros(1)
+        mb = self.motion_bases.params
+        m, q, _ = poses(means, quats, coefs, mb["rots"] if coefs is not None else None,
+                        mb["transls"] if coefs is not None else None, _ts1d(ts))
+        return m, q
+
+    def compute_poses_fg(self, ts: torch.Tensor | None, inds: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """-> means (G,B,3), quats (G,B,4) wxyz (scene_model.py:76-106)."""
+        means, quats, coefs = self.fg.params["means"], self.fg.params["quats"], self.fg.params["motion_coefs"]
+        if inds is not None:
+            means, quats, coefs = means[inds], quats[inds], coefs[inds]
+        return self._poses(means, quats, coefs, ts)
+
+    def compute_poses_all(self, ts: torch.Tensor | None) -> tuple[torch.Tensor, torch.Tensor]:
+        """-> means (N,B,3), quats (N,B,4): fg rows deformed, bg rows repeated (scene_model.py:108-120).  One launch over
+        the concatenated raw leaves (the static rows pass through the same kernel)."""
+        P = self._raw("all")
+        return self._poses(P["means"], P["quats"], self.fg.params["motion_coefs"], ts)
 
     def _raw(self, which: str):
         sets = {"fg": [self.fg], "bg": [self.bg], "all": [self.fg] + ([self.bg] if self.bg is not None else [])}[which]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D4GS_VERSION 201
+#define D4GS_VERSION 300
 #define D4GS_TILE 16
 #define D4GS_GEOM_STRIDE 8 /* floats per instance record: x, y, opacity, depth, conic a, b, c, pad */
 
@@ -50,6 +50,9 @@ enum { /* D4gsDims.flags */
 };
 
 enum { D4GS_DEPTH_NONE = 0, D4GS_DEPTH_ED = 1, D4GS_DEPTH_D = 2 }; /* render_mode RGB / RGB+ED / RGB+D */
+/* D4gsRasterGrads.row_mode.  DENSE: every row of isect_grad is written (rows behind a tile's last contributor zero-filled);
+ * SPARSE: only replayed rows are written and flagged in isect_live (large-footprint / occluded scenes).  Same gradients, bitwise. */
+enum { D4GS_ROWS_AUTO = 0, D4GS_ROWS_DENSE = 1, D4GS_ROWS_SPARSE = 2 };
 
 typedef struct D4gsDims {
   int32_t N;          /* Gaussians */
@@ -152,6 +155,7 @@ typedef struct D4gsRasterGrads {
   float *stats_max_radii;       /* [N] */
   int32_t stats_batch_size;
   int32_t stats_update_max_radii;
+  int32_t row_mode;             /* D4GS_ROWS_*: AUTO picks dense / sparse rows from the list capacity per instance */
 } D4gsRasterGrads;
 
 /* leaf gradients produced by d4gs_project_bwd (all overwritten, not accumulated) */
@@ -219,6 +223,27 @@ int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
 int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points /* [S,N,3] */, void *stream);
 int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points /* [S,N,3] */,
                     const D4gsLeafGrads *grads, void *stream);
+
+/* a4/a5 pose API of the S2 seam (flow3d/scene_model.py:58-120; called by the reference's Trainer at
+ * flow3d/trainer.py:303,478,485,701,818 and its Renderer at flow3d/renderer.py:37): for the S = B times in in->times
+ *   transforms[g,b] = [cont_6d_to_rmat(r6) | transl] of the time-blended, coefficient-weighted bases   (G dynamic rows)
+ *   means[g,b]      = R means_g + transl                          (static rows g >= G: means_g)
+ *   quats[g,b]      = normalize( wxyz( rotmat_to_unitquat(R)_xyzw (x) xyzw(normalize(quats_g)) ) )   (static: normalize)
+ * Uses dims N/G/K/T/S and in->means, quats (only when `quats` is requested), motion_coefs, rots, transls, times; in->RTs
+ * [S,3,4] and in->viewmat (both optional, NULL = identity) are applied to the MEANS only - that is d4gs_points_fwd, the
+ * a11 track channels.  Any of the three outputs may be NULL.  g_major selects the layout: 0 = time-major [S,N,...]
+ * ([S,G,3,4] for transforms), 1 = the reference's Gaussian-major (G,B,...) tensors.
+ * d4gs_poses_bwd takes the three gradients in the same struct (NULL = zero) and fills v_means, v_quats (if quats'
+ * gradient was given and v_quats != NULL), v_motion_coefs, v_rots, v_transls, v_times, v_RTs of D4gsLeafGrads. */
+typedef struct D4gsPoses {
+  float *means;       /* [S,N,3] | [N,S,3] */
+  float *quats;       /* [S,N,4] | [N,S,4]  wxyz, unit */
+  float *transforms;  /* [S,G,3,4] | [G,S,3,4] */
+  int32_t g_major;
+} D4gsPoses;
+int d4gs_poses_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *out, void *stream);
+int d4gs_poses_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *v_out, const D4gsLeafGrads *grads,
+                   void *stream);
 
 /* Densification statistics, Trainer._prepare_control_step (flow3d/trainer.py:953-990) for one render of
  * S sub-samples: for every visible instance (radii > 0)

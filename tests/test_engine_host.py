@@ -1,4 +1,5 @@
 """Host-side logic of the engine that needs no GPU: channel chunking, sort size classes, the bounded size-guess cache."""
+import pytest
 import torch
 
 from deblur4dgs_amd import engine
@@ -50,3 +51,32 @@ def test_control_stats_sink_is_validated():
         engine._check_stats({**good, "vis_count": torch.zeros(5)}, 5)
     with pytest.raises(ValueError):
         engine._check_stats({**good, "batch_size": 0}, 5)
+
+
+def test_deferred_records_queue_up_and_are_all_verified():
+    """Host logic of `deferred_size_check` without a GPU: several pending records per shape, every one is read, an
+    overflow in ANY of them raises (only the newest used to survive)."""
+    from deblur4dgs_amd import engine
+
+    class Ev:
+        def __init__(self, done):
+            self.done = done
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.done = True
+
+    key = ("unit", 1, 2, 3, 4)
+    mk = lambda n, mt: torch.tensor([n, mt], dtype=torch.int64)
+    engine._DEFERRED[key] = [(mk(100, 10), Ev(True), 200, 2048), (mk(900, 10), Ev(True), 200, 2048),
+                             (mk(120, 10), Ev(False), 200, 2048)]
+    with pytest.raises(RuntimeError, match="needed 900 intersections"):
+        engine._deferred_poll(key)           # reads the two that have landed; the second one overflowed
+    assert len(engine._DEFERRED[key]) == 1   # the pending one is still queued
+    assert engine._guess_get(key)[0] >= 900  # the guess follows the largest count seen
+    assert engine._deferred_poll(key) is None and len(engine._DEFERRED[key]) == 1  # not landed yet, non-blocking
+    engine.check_deferred()                  # blocking drain: fits, no error
+    assert key not in engine._DEFERRED
+    engine._SIZE_GUESS.pop(key, None)

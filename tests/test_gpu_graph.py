@@ -57,6 +57,40 @@ def test_deferred_size_check_equals_the_synchronous_path_and_reports_overflow_on
     assert torch.equal(r2["blended"], r3["blended"]) and torch.equal(again["means"].grad, sync["means"].grad)
 
 
+def test_every_deferred_render_of_a_step_is_verified_not_only_the_last():
+    """a step that issues several same-shape renders before any count has landed used to keep only
+    the newest pending record, so an EARLIER render that overflowed went unnoticed (garbage images, zero gradients).
+    Three renders of one shape, the first one overflowing, one check_deferred() at the end: it must raise; and the
+    overflowed render's gather must not fault on the never-written offsets (k_gather)."""
+    from deblur4dgs_amd import engine
+
+    dev = torch.device("cuda:0")
+    N, G, K_, S, W, H = 6000, 4000, 4, 3, 160, 96
+    sc = make_scene(N, G, K_, S, W, H, seed=8)
+    K = sc["K"].to(dev)
+    w = torch.randn(H, W, 4, generator=torch.Generator().manual_seed(0)).to(dev)
+    engine.check_deferred()
+    engine._SIZE_GUESS.clear()
+    _step(_leaves(sc, dev), K, W, H, w)  # synchronous warm-up: leaves the guess of the small scene
+    big, small1, small2 = _leaves(sc, dev, scale_add=2.1), _leaves(sc, dev), _leaves(sc, dev)
+    key = next(iter(engine._SIZE_GUESS))
+    guess = engine._SIZE_GUESS[key]
+    _step(big, K, W, H, w, deferred_size_check=True)     # overflows the guess
+    engine._SIZE_GUESS[key] = guess                       # (a poll between the renders may have raised the guess already)
+    try:
+        _step(small1, K, W, H, w, deferred_size_check=True)
+        _step(small2, K, W, H, w, deferred_size_check=True)
+        raised = False
+    except RuntimeError as e:  # the count of `big` may already have landed at one of the later calls: also fine
+        raised = "INVALID" in str(e)
+    if not raised:
+        with pytest.raises(RuntimeError, match="INVALID"):
+            engine.check_deferred()
+    engine.check_deferred()  # drained: nothing left to complain about
+    torch.cuda.synchronize()
+    assert float(big["means"].grad.abs().sum()) == 0.0  # the overflowed render's gradients are zeros, not a fault
+
+
 def test_whole_render_forward_and_backward_replays_from_a_hip_graph():
     dev = torch.device("cuda:0")
     N, G, K_, S, W, H = 20000, 12000, 4, 4, 256, 144

@@ -152,7 +152,7 @@ def test_sparse_and_dense_gradient_rows_agree_bitwise(mode, D, monkeypatch):
     #                                                    entries, most of each list lies behind the last contributor
     grads = {}
     for rows in ("dense", "sparse"):
-        monkeypatch.setenv("D4GS_BWD_ROWS", rows)
+        monkeypatch.setattr("deblur4dgs_amd.engine.BWD_ROWS", rows)
         rc, ra, info, tg = _run_gpu(inp, W, H, mode, torch.ones(D), requires_grad=True)
         info["means2d"].retain_grad()
         (rc.square().sum() + 0.5 * ra.sum()).backward()
@@ -242,8 +242,14 @@ torch.cuda.synchronize()
 torch.save((rc.cpu(), ra.cpu(), info["last_ids"].cpu()), sys.argv[1])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env_extra, name in (({}, "/tmp/d4gs_fwd_b.pt"), ({"D4GS_FWD_WAVE_PER_TILE": "1"}, "/tmp/d4gs_fwd_a.pt"),
-                            ({"D4GS_FWD_ROWS": "1"}, "/tmp/d4gs_fwd_d.pt"), ({"D4GS_FWD_QUADS": "1"}, "/tmp/d4gs_fwd_q.pt")):
+    from deblur4dgs_amd import build
+
+    # the reference variants A / B live only in the A/B build (tests/libd4gs_variants.so, -DD4GS_VARIANTS); the first run
+    # is the shipped library (k_raster_fwd_r)
+    var = {"D4GS_LIB_PATH": build.VARIANTS_LIB}
+    assert os.path.exists(build.VARIANTS_LIB), "run __graft_entry__.build() (builds tests/libd4gs_variants.so)"
+    for env_extra, name in (({}, "/tmp/d4gs_fwd_b.pt"), ({**var, "D4GS_FWD_WAVE_PER_TILE": "1"}, "/tmp/d4gs_fwd_a.pt"),
+                            (var, "/tmp/d4gs_fwd_d.pt"), ({**var, "D4GS_FWD_QUADS": "1"}, "/tmp/d4gs_fwd_q.pt")):
         env = {k: v for k, v in os.environ.items() if not k.startswith("D4GS_FWD_")}
         env.update(env_extra)
         subprocess.check_call([sys.executable, "-c", code, name], env=env)
@@ -478,8 +484,12 @@ torch.cuda.synchronize()
 torch.save([t[k].grad.cpu() for k in ("means", "quats", "scales", "opac", "colors")], sys.argv[1])
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), D)
     outs = []
-    for env_extra, name in (({}, "/tmp/d4gs_bwd_b.pt"), ({"D4GS_BWD_WAVE_PER_TILE": "1"}, "/tmp/d4gs_bwd_a.pt"),
-                            ({"D4GS_BWD_MFMA": "1"}, "/tmp/d4gs_bwd_c.pt")):
+    from deblur4dgs_amd import build
+
+    var = {"D4GS_LIB_PATH": build.VARIANTS_LIB}  # variants A / C exist only in the A/B build (-DD4GS_VARIANTS)
+    assert os.path.exists(build.VARIANTS_LIB), "run __graft_entry__.build() (builds tests/libd4gs_variants.so)"
+    for env_extra, name in (({}, "/tmp/d4gs_bwd_b.pt"), ({**var, "D4GS_BWD_WAVE_PER_TILE": "1"}, "/tmp/d4gs_bwd_a.pt"),
+                            ({**var, "D4GS_BWD_MFMA": "1"}, "/tmp/d4gs_bwd_c.pt")):
         env = {k: v for k, v in os.environ.items() if not k.startswith("D4GS_BWD_")}
         env.update(env_extra)
         subprocess.check_call([sys.executable, "-c", code, name], env=env)
