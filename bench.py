@@ -76,6 +76,12 @@ def parse():
                          "library's default); without the flag the counts are verified once per step behind the launches "
                          "(`deferred_size_check` + `engine.check_deferred()`, as examples/train_dynamic_step.py does), so "
                          "the host may run a frame ahead and a slow host does not stall the GPU")
+    ap.add_argument("--staged", action="store_true",
+                    help="drive the five staged C entry points through three autograd nodes (ProjectFn / RasterFn / BlendFn) "
+                         "instead of the one-call d4gs_forward / d4gs_backward node (same kernels, more host work)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="with --gpus N > 1: time the eager step (host-bound: ~40 launches + 3 collectives per step) "
+                         "instead of the captured one")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step (render forward + backward, deferred size check) in a HIP graph and time its "
                          "replays (with --gpus N > 1 / --force-dist the RCCL collectives are captured too: verified at world size 1 only)")
@@ -273,6 +279,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
+    # N > 1: the sharded step leaves each rank a fraction of a millisecond of device work behind ~1 ms of host launch work,
+    # so the captured step (one hipGraphLaunch, RCCL collectives inside) is the default there; --no-graph times the eager one
+    graph_default = world > 1 and not args.graph and not args.no_graph
+    if graph_default:
+        args.graph = True
     if use_dist:
         import torch.distributed as dist
 
@@ -312,17 +323,21 @@ def main():
             got[nm] = (int(cnt), float(ms))
         return got
 
+    graph_note = {}
+
     def measure(mode, steps, warmup, profile):
         """-> (seconds for `steps` steps: max over ranks, live kernel timings, last state)"""
         views = use_dist and mode == "views"
         sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0, channels=channels,
                                                 scale_mul=args.scale_mul)
         sharder = ShardedExposure(world, rank, mode=mode) if use_dist else None
+        if sharder is not None:
+            sharder.fused = not args.staged
         deferred = not args.sync_size_check
         if sharder is not None:
             sharder.deferred_size_check = deferred
         last = {}
-        mode_flag = {"deferred": deferred}
+        mode_flag = {"deferred": deferred, "fused": not args.staged}
 
         def step():
             for v in leaves.values():
@@ -331,7 +346,7 @@ def main():
                 res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                       leaves["colors"], 3, leaves.get("motion_coefs"), leaves.get("rots"),
                                       leaves.get("transls"), leaves.get("times"), leaves["RTs"], leaves["viewmat"], d["K"],
-                                      W, H, background=bg, return_depth=True, deferred_size_check=mode_flag["deferred"])
+                                      W, H, background=bg, return_depth=True, deferred_size_check=mode_flag["deferred"], fused=mode_flag["fused"])
                 loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
                 loss.backward()
                 last["st"] = res["state"]
@@ -364,7 +379,7 @@ def main():
                 res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                       leaves["colors"], 3, leaves.get("motion_coefs"), leaves.get("rots"),
                                       leaves.get("transls"), leaves.get("times"), leaves["RTs"], leaves["viewmat"], d["K"],
-                                      W, H, background=bg, return_depth=True, deferred_size_check=True)
+                                      W, H, background=bg, return_depth=True, deferred_size_check=True, fused=mode_flag["fused"])
                 loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
                 loss.backward()
                 return res["state"]
@@ -377,16 +392,25 @@ def main():
                 for v in leaves.values():
                     v.grad = None
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                gstep()
+            try:
+                with torch.cuda.graph(graph):
+                    gstep()
+                captured = True
+            except Exception as e:  # (never seen at world size 1; an N > 1 capture has not run on this pool's 1-GPU boxes)
+                captured = False
+                graph_note["fallback"] = f"graph capture failed ({type(e).__name__}: {e}); timed the eager step"
+                sys.stderr.write(graph_note["fallback"] + "\n")
+                torch.cuda.synchronize()
+            if captured:
+                def step():  # noqa: F811
+                    graph.replay()
+                    last["st"] = real_state  # exact list sizes of the same scene (the captured state holds capacities)
 
-            def step():  # noqa: F811
-                graph.replay()
-                last["st"] = real_state  # exact list sizes of the same scene (the captured state holds capacities)
-
-            for _ in range(3):
-                step()
-            sync()
+                for _ in range(3):
+                    step()
+                sync()
+            elif sharder is not None:
+                sharder.deferred_size_check = deferred
         if profile:
             lib.d4gs_profile_enable(2)  # HIP events around the rasterization kernels only: timing EVERY kernel costs two
         t0 = time.perf_counter()      # stream events per launch, ~0.12 ms of a 1.6 ms frame
@@ -403,9 +427,11 @@ def main():
                 step()
             sync()
             kern_all = collect()
-        if deferred and not args.graph:  # one untimed step with the host-checked sizes: its state carries the EXACT counts
-            mode_flag["deferred"] = False  # (a deferred state only knows its capacities) for the byte / pair accounting
+        if not args.graph:  # one untimed STAGED step with host-checked sizes: its state carries the exact counts and the
+            mode_flag["deferred"] = False  # per-stage buffers (tile offsets, last ids) of the byte / pair accounting below
+            mode_flag["fused"] = False
             if sharder is not None:
+                sharder.fused = False
                 sharder.deferred_size_check = False
             step()
             sync()
@@ -438,8 +464,9 @@ def main():
     out["config"]["size_check"] = ("host waits for every render's intersection counts" if args.sync_size_check else
                                    "intersection counts verified once per step behind the launches (deferred)")
     if args.graph:
-        out["config"]["launch"] = ("one HIP graph per step (render forward + backward" + (" + RCCL collectives" if use_dist else "")
-                                   + " captured, deferred size check)")
+        out["config"]["launch"] = graph_note.get("fallback") or (
+            "one HIP graph per step (render forward + backward" + (" + RCCL collectives" if use_dist else "")
+            + " captured, deferred size check)" + ("; default for N > 1, --no-graph times the eager step" if graph_default else ""))
     if world > 1 and not views_primary:  # secondary: data-parallel over camera views (weak scaling), same protocol
         dt_v, _, _, _, _ = measure("views", args.steps, args.warmup, False)
         out["views_weak_scaling"] = {"value": world * N / (dt_v / args.steps), "unit": "Gaussians/s", "scaling": "weak",

@@ -72,6 +72,22 @@ class LeafGrads(C.Structure):
                                  "v_rots", "v_transls", "v_times", "v_RTs", "v_viewmat", "partials")]
 
 
+class ShardBlend(C.Structure):
+    _fields_ = [("S_total", C.c_int32), ("S_local", C.c_int32), ("s_first", C.c_int32), ("s_stride", C.c_int32), ("C", C.c_int32),
+                ("n_pixels", C.c_int64), ("policy", C.POINTER(C.c_int32))]
+
+
+class FrameIO(C.Structure):
+    _fields_ = [(n, F) for n in ("blended", "acc", "renders", "alphas", "means2d", "radii", "n_isect", "background")] + \
+               [("policy", C.POINTER(C.c_int32))]
+
+
+class FrameGrads(C.Structure):
+    _fields_ = [(n, F) for n in ("v_blended", "v_acc", "v_renders", "v_alphas", "v_means2d", "stats_grad_norm_acc",
+                                 "stats_vis_count", "stats_max_radii")] + \
+               [("stats_batch_size", C.c_int32), ("stats_update_max_radii", C.c_int32), ("row_mode", C.c_int32)]
+
+
 class Poses(C.Structure):
     _fields_ = [("means", F), ("quats", F), ("transforms", F), ("g_major", C.c_int32)]
 
@@ -86,7 +102,8 @@ GEOM_STRIDE = 8
 EXPORTS = (
     "d4gs_version", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
-    "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_poses_fwd", "d4gs_poses_bwd", "d4gs_control_stats", "d4gs_control_plan", "d4gs_gather_rows", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
+    "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_poses_fwd", "d4gs_poses_bwd", "d4gs_forward", "d4gs_backward", "d4gs_frame_workspace_bytes", "d4gs_blend_shard_partial_fwd", "d4gs_blend_shard_finish_fwd",
+    "d4gs_blend_shard_winner", "d4gs_blend_shard_bwd", "d4gs_control_stats", "d4gs_control_plan", "d4gs_gather_rows", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
     "d4gs_pose_encode", "d4gs_pose_encode_bwd", "d4gs_move_model_fwd", "d4gs_move_model_bwd",
     "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_query_sizes", "d4gs_profile_enable", "d4gs_profile_collect",
 )
@@ -122,6 +139,15 @@ def lib() -> C.CDLL:
         L.d4gs_points_bwd.argtypes = [P(Dims), P(ProjIn), vp, P(LeafGrads), vp]
         L.d4gs_poses_fwd.argtypes = [P(Dims), P(ProjIn), P(Poses), vp]
         L.d4gs_poses_bwd.argtypes = [P(Dims), P(ProjIn), P(Poses), P(LeafGrads), vp]
+        L.d4gs_blend_shard_partial_fwd.argtypes = [P(ShardBlend), vp, vp, vp, vp, vp]
+        L.d4gs_blend_shard_finish_fwd.argtypes = [P(ShardBlend), vp, vp, vp, vp, vp]
+        L.d4gs_blend_shard_winner.argtypes = [P(ShardBlend), vp, vp, vp, vp]
+        L.d4gs_blend_shard_bwd.argtypes = [P(ShardBlend), vp, vp, vp, vp, vp, vp]
+        L.d4gs_frame_workspace_bytes.argtypes = [P(Dims), C.c_int64]
+        L.d4gs_frame_workspace_bytes.restype = C.c_size_t
+        L.d4gs_forward.argtypes = [P(Dims), P(ProjIn), P(FrameIO), vp, C.c_size_t, C.c_int64, C.c_int64, vp]
+        L.d4gs_backward.argtypes = [P(Dims), P(ProjIn), P(FrameIO), P(FrameGrads), P(LeafGrads), vp, C.c_size_t, C.c_int64,
+                                    C.c_int64, vp]
         L.d4gs_control_stats.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, vp]
         L.d4gs_control_plan.argtypes = [C.c_int32, vp, vp, vp, vp, vp]
         L.d4gs_gather_rows.argtypes = [vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, C.c_int64, C.c_float, vp]

@@ -25,6 +25,8 @@ int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float 
 int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
                         const float *, float *, float *, hipStream_t);
 
+int d4gs_blend_shard_impl(int, const D4gsShardBlend *, const void *, const void *, const void *, void *, void *, hipStream_t);
+
 int d4gs_pose_encode_impl(const float *, int32_t, const float *, int32_t, float *, hipStream_t);
 int d4gs_camera_path_fwd_impl(const float *, const float *, int32_t, const float *, int32_t, float, int32_t, float *,
                               float *, float *, float *, float *, hipStream_t);
@@ -352,6 +354,41 @@ int d4gs_blend_bwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy
                    void *stream) {
   return d4gs_blend_bwd_impl(S, n_pixels, C, policy, renders, out, v_out, v_acc, v_renders, v_alphas,
                              (hipStream_t)stream);
+}
+
+int d4gs_blend_shard_partial_fwd(const D4gsShardBlend *b, const float *renders, const float *alphas, float *part, float *cand,
+                                 void *stream) {
+  if (!part || (b && b->S_local > 0 && (!renders || !alphas))) {
+    d4gs_set_error("blend_shard_partial_fwd: NULL buffer");
+    return D4GS_EINVAL;
+  }
+  return d4gs_blend_shard_impl(0, b, renders, alphas, nullptr, part, cand, (hipStream_t)stream);
+}
+
+int d4gs_blend_shard_finish_fwd(const D4gsShardBlend *b, const float *part, const float *cand, float *out, float *acc,
+                                void *stream) {
+  if (!part || !out || !acc) {
+    d4gs_set_error("blend_shard_finish_fwd: NULL buffer");
+    return D4GS_EINVAL;
+  }
+  return d4gs_blend_shard_impl(1, b, part, cand, nullptr, out, acc, (hipStream_t)stream);
+}
+
+int d4gs_blend_shard_winner(const D4gsShardBlend *b, const float *renders, const float *out, int32_t *win, void *stream) {
+  if (!out || !win) {
+    d4gs_set_error("blend_shard_winner: NULL buffer");
+    return D4GS_EINVAL;
+  }
+  return d4gs_blend_shard_impl(2, b, renders, out, nullptr, win, nullptr, (hipStream_t)stream);
+}
+
+int d4gs_blend_shard_bwd(const D4gsShardBlend *b, const float *v_out, const float *v_acc, const int32_t *win,
+                         float *v_renders, float *v_alphas, void *stream) {
+  if (!v_out || (b && b->S_local > 0 && (!v_renders || !v_alphas))) {
+    d4gs_set_error("blend_shard_bwd: NULL buffer");
+    return D4GS_EINVAL;
+  }
+  return d4gs_blend_shard_impl(3, b, v_out, v_acc, win, v_renders, v_alphas, (hipStream_t)stream);
 }
 
 int d4gs_pose_encode(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc, void *stream) {

@@ -22,8 +22,9 @@ namespace {
 constexpr int BLK = 256;
 constexpr int GPB = 64;   // Gaussians per block = lanes of a wave
 constexpr int SLOTS = 4;  // sub-sample slots = waves of a block
-constexpr int NACC = 23;  // per-lane accumulators, kept in LDS (ds_add_f32 by their owner lane only): v_mu 3, v_q 4, v_sc 3,
-                          // v_view 12 (+1: odd stride)
+// per-lane accumulators kept in LDS (read-modify-write by their owner lane only): v_mu 3, v_q 4, v_sc 3, v_view 12 (+1: odd
+// stride).  The K > 8 variant is LDS-bound in occupancy (coefficient gradients [256][K]), so it keeps v_view in registers.
+constexpr int nacc_of(bool mfma) { return mfma ? 11 : 23; }
 enum { MODE_RENDER = 0, MODE_POSES = 1 };
 
 struct BwdArgs {
@@ -44,6 +45,9 @@ struct BwdArgs {
   int persist;                // 1: a fixed grid of blocks walks the 64-Gaussian groups and keeps its shared-gradient sums in LDS
 };
 
+#ifndef PB_MFMA_WAVES
+#define PB_MFMA_WAVES 3
+#endif
 #ifndef PB_NO_SB
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -52,6 +56,11 @@ struct BwdArgs {
 // accumulate into the lane's private LDS row: plain read-modify-write (ds_add_f32, 22 per pass, measured 2.6x slower for the
 // whole kernel: 306 vs 117 us on cfg2 - LDS float atomics run at a fraction of the plain DS rate on gfx950)
 #define ACC(slot_, val_) ac[slot_] += (val_)
+#define VIEW(i_, val_)                     \
+  do {                                     \
+    if constexpr (MFMA) v_view_r[i_] += (val_); \
+    else ac[10 + (i_)] += (val_);           \
+  } while (0)
 
 // v_q += (d R(q) / d q)^T vR for a unit quaternion q = (w, x, y, z)
 __device__ __forceinline__ void rotmat_adj_to_quat(const float *q, const float *vR, float *v_q) {
@@ -63,7 +72,7 @@ __device__ __forceinline__ void rotmat_adj_to_quat(const float *q, const float *
 }
 
 template <int MODE, bool MFMA /* K > 8: basis-gradient column sums on the matrix pipe */>
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ? 3 : 4))) k_project_bwd(const BwdArgs a) {
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ? PB_MFMA_WAVES : 4))) k_project_bwd(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const D4gsDims &d = a.d;
   const int N = d.N, G = d.G, S = d.S;
@@ -77,6 +86,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   float *vcf = cf + GPB * KP;         // [BLK][KP]    their gradients, per slot, summed over the slot's sub-samples
   float *bsl = vcf + BLK * KP;        // [SLOTS][2][nk4] time-blended bases of the sub-sample each wave is working on / will work on next
   float *red = bsl + 2 * SLOTS * nk4; // [SLOTS][nop] per-wave reduction slab (+ dump slot)
+  constexpr int NACC = nacc_of(MFMA);
   float *accs = red + SLOTS * nop;    // [BLK][NACC]  per-lane leaf accumulators (cross-slot sum at the end)
   float *svec = accs + BLK * NACC;    // [BLK][9]     K > 8 only: (v_transl 3, v_r6 6) of every lane, MFMA B operand
   const int tid = threadIdx.x;
@@ -143,6 +153,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   float *ac = accs + tid * NACC;  // [0:3] v_mu, [3:7] v_q, [7:10] sc * v_sc, [10:22] dL/dRcw (9, row-major) then dL/dt (3)
 #pragma unroll
   for (int c = 0; c < NACC - 1; c++) ac[c] = 0.f;
+  float v_view_r[MFMA ? 12 : 1];
+#pragma unroll
+  for (int c = 0; c < (MFMA ? 12 : 1); c++) v_view_r[c] = 0.f;
   float *part = a.persist ? wacc : a.g.partials + (size_t)grp * a.n_shared;
   float *mine = red + slot * nop;
 
@@ -339,8 +352,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
 #pragma unroll
           for (int r = 0; r < 3; r++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) ACC(10 + r * 3 + c, tmp[r * 3 + c] + v_pc[r] * mw[c]);
-            ACC(19 + r, v_pc[r]);
+            for (int c = 0; c < 3; c++) VIEW(r * 3 + c, tmp[r * 3 + c] + v_pc[r] * mw[c]);
+            VIEW(9 + r, v_pc[r]);
           }
         }
         mat3_mul_at(cam.R, vW, vRm);  // Rcw^T vW
@@ -534,7 +547,10 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   {
     float v_view[12];
 #pragma unroll
-    for (int c = 0; c < 12; c++) v_view[c] = ac[10 + c];
+    for (int c = 0; c < 12; c++) {
+      if constexpr (MFMA) v_view[c] = v_view_r[c];
+      else v_view[c] = ac[10 + c];
+    }
     wave_sum_store(v_view, mine, 0, lane);
   }
   __syncthreads();
@@ -689,37 +705,87 @@ int n_shared_of(const D4gsDims *d) { return d->S * ((d->G > 0 ? d->K * 9 : 0) + 
 
 }  // namespace
 
-constexpr int PERSIST_BLOCKS = 1024;      // 256 CUs x 4 resident blocks; a constant, so the summation order (hence every bit of
-                                          // the result) does not depend on the device the kernel runs on
 constexpr int PERSIST_MAX_SHARED = 8192;  // floats of LDS a block may spend on its shared-gradient sums
-static bool use_persist(const D4gsDims *d) { return n_shared_of(d) <= PERSIST_MAX_SHARED; }
-static size_t partial_blocks(const D4gsDims *d) {
-  const size_t groups = ((size_t)d->N + GPB - 1) / GPB;
-  return use_persist(d) && groups > PERSIST_BLOCKS ? PERSIST_BLOCKS : groups;
+
+// The persistent grid is exactly what the device keeps resident (CUs x blocks per CU for this kernel's registers and
+// LDS): no second, partially filled round of blocks.  Cached per (device, kernel, LDS size); the summation order of the
+// shared gradients follows the grid size, so results are bit-reproducible on a given device model, not across models.
+// -> 0 when there is no device to ask (the size query of a GPU-less host).
+static int resident_blocks(const void *fn, size_t lds) {
+  struct Entry { int dev; const void *fn; size_t lds; int blocks; };
+  thread_local Entry cache[8];
+  thread_local int n_cache = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  for (int i = 0; i < n_cache; i++)
+    if (cache[i].dev == dev && cache[i].fn == fn && cache[i].lds == lds) return cache[i].blocks;
+  int cus = 0, per = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, BLK, lds) != hipSuccess || per < 1 || cus < 1) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (n_cache < 8) cache[n_cache++] = Entry{dev, fn, lds, cus * per};
+  return cus * per;
+}
+
+// launch shape of k_project_bwd for one configuration: grid, LDS bytes, persistent or one group per block
+struct BwdPlan {
+  int blocks, persist;
+  size_t lds;
+  const void *fn;
+};
+template <int MODE>
+static BwdPlan plan_bwd(const D4gsDims *dims) {
+  BwdPlan p;
+  const int K = dims->G > 0 ? dims->K : 0;
+  const int KP = K | 1;
+  const size_t nk = (size_t)K * 9;
+  const int n_shared = n_shared_of(dims);
+  p.fn = K > 8 ? (const void *)k_project_bwd<MODE, true> : (const void *)k_project_bwd<MODE, false>;
+  auto lds_of = [&](bool persist) {
+    return sizeof(float) * ((size_t)GPB * KP + (size_t)BLK * KP + 2 * SLOTS * ((nk + 3) & ~(size_t)3) + SLOTS * (nk + 13) +
+                            (size_t)BLK * nacc_of(K > 8) + (K > 8 ? (size_t)BLK * 9 : 0) + (persist ? (size_t)n_shared : 0));
+  };
+  p.blocks = (dims->N + GPB - 1) / GPB;
+  p.persist = 0;
+  p.lds = lds_of(false);
+  if (n_shared <= PERSIST_MAX_SHARED) {
+    // Persistent blocks are worth it when every block walks many groups, or when all groups cost the same: a block's
+    // groups are b, b + grid, ..., so a scene with few groups per block AND two kinds of groups (dynamic ones cost ~2.5x a
+    // static one; the reference's 40 k + 100 k training shape: 2.8 groups per block) is balanced better by the hardware's
+    // own block scheduler - measured 113 us one group per block against 146 us persistent (cfg5, 20 groups per block:
+    // 1149 against 1012 us).
+    const int res = resident_blocks(p.fn, lds_of(true));
+    const bool uniform = dims->G == 0 || dims->G == dims->N;
+    if (res > 0 && p.blocks >= (uniform ? 2 : 8) * res) p.blocks = res, p.persist = 1, p.lds = lds_of(true);
+  }
+  return p;
 }
 
 extern "C" size_t d4gs_bwd_partials_elems(const D4gsDims *d) {
-  return (partial_blocks(d) + RCH + 1) * (size_t)n_shared_of(d);
+  // (the render and the poses instantiation have different register counts: take the larger grid of the two)
+  const int b0 = plan_bwd<MODE_RENDER>(d).blocks, b1 = plan_bwd<MODE_POSES>(d).blocks;
+  return ((size_t)(b0 > b1 ? b0 : b1) + RCH + 1) * (size_t)n_shared_of(d);
 }
 
 template <int MODE>
 static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGrads *grads, hipStream_t stream) {
   a.n_shared = n_shared_of(dims);
-  a.persist = use_persist(dims) ? 1 : 0;
+  const BwdPlan pl = plan_bwd<MODE>(dims);
+  a.persist = pl.persist;
   const int K = dims->G > 0 ? dims->K : 0;
-  const int KP = K | 1;
-  const size_t nk = (size_t)K * 9;
-  size_t lds = sizeof(float) * ((size_t)GPB * KP + (size_t)BLK * KP + 2 * SLOTS * ((nk + 3) & ~(size_t)3) + SLOTS * (nk + 13) +
-                                (size_t)BLK * NACC + (K > 8 ? (size_t)BLK * 9 : 0) + (a.persist ? (size_t)a.n_shared : 0));
+  const size_t lds = pl.lds;
+  const int blocks = pl.blocks;
   if (lds > 160 * 1024) {
     d4gs_set_error("project_bwd: LDS budget exceeded (K=%d)", dims->K);
     return D4GS_EINVAL;
   }
-  if (lds > 64 * 1024) {  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
-    if (K > 8) (void)hipFuncSetAttribute((const void *)k_project_bwd<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    else (void)hipFuncSetAttribute((const void *)k_project_bwd<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
-  const int blocks = (int)partial_blocks(dims);
+  if (lds > 64 * 1024)  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
+    (void)hipFuncSetAttribute(pl.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const char *name = MODE == MODE_RENDER ? "k_project_bwd" : "k_project_bwd[poses]";
   if (K > 8) D4GS_LAUNCH(name, (k_project_bwd<MODE, true>), dim3(blocks), dim3(BLK), lds, stream, a);
   else D4GS_LAUNCH(name, (k_project_bwd<MODE, false>), dim3(blocks), dim3(BLK), lds, stream, a);

@@ -84,6 +84,15 @@ class State:
     n_isect: int = -1
     max_tile: int = -1
     binned: bool = False
+    # one-call path (FrameFn)
+    ws: object = None
+    ws_ptr: int = 0
+    ws_bytes: int = 0
+    ws_cap: tuple = (0, 0)
+    frame_io: dict = field(default_factory=dict)
+    policy: object = None
+    xys_sink: list | None = None
+    v_means2d: object = None
 
 
 BWD_ROWS = "auto"  # "auto" | "dense" | "sparse": gradient-row mode of the composite backward (D4gsRasterGrads.row_mode);
@@ -338,6 +347,57 @@ def _check_stats(cs: dict, N: int) -> dict:
     return cs
 
 
+def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch: bool = False):
+    """The intersection-list size protocol shared by the staged and the one-call path.  `launch(capacity, max_tile_hint)`
+    allocates the lists and enqueues binning + rasterization (every kernel checks the device-side count against the
+    capacity); `n_isect_dev()` is the device int64[2] {count, longest tile list} of the launch just made (staged path:
+    already there, the projection ran before; one-call path, `count_needs_launch`: a capacity-0 call whose list kernels
+    all return at once does the counting).  -> (capacity or exact count, max-tile value) the backward must use."""
+    key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
+    if cfg.deferred_size_check:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            _deferred_poll(key)  # raises if an earlier render of this shape overflowed
+        guess = _guess_get(key)
+        if guess is not None:
+            # deferred check: launch at the guessed capacity, never wait.  The count travels to pinned memory behind
+            # the launches and is looked at by a later call (not under stream capture: a graph replays this shape).
+            launch(*guess)
+            if not capturing:
+                with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
+                    host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
+                if host_n is None:
+                    host_n = torch.empty(2, dtype=torch.int64).pin_memory()
+                host_n.copy_(n_isect_dev(), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                with _SIZE_LOCK:
+                    _DEFERRED.setdefault(key, []).append((host_n, ev, guess[0], guess[1]))
+            _SIZE_STATS["calls"] += 1
+            return guess
+    # The list sizes live on the device.  Read them back through pinned memory; when a previous call of the same
+    # shape left a guess, launch binning + rasterization FIRST (sized by the guess, checked on the device) and
+    # wait for the counts afterwards, so the GPU never idles on the host round trip (70 us per render).
+    guess = _guess_get(key) if cfg.optimistic_sizes else None
+    if guess is not None:
+        launch(*guess)
+    elif count_needs_launch:
+        launch(0, 0)
+    host_n = _pinned_counts(dev)
+    host_n.copy_(n_isect_dev(), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ev.synchronize()
+    n, max_tile = host_n.tolist()
+    if guess is None or n > guess[0] or (guess[1] > 0 and max_tile > guess[1]):
+        if guess is not None:
+            _SIZE_STATS["relaunched"] += 1
+        launch(n, max_tile)
+    _SIZE_STATS["calls"] += 1
+    _guess_put(key, (n + n // 4 + 4096, _sort_class(max_tile)))
+    return n, max_tile
+
+
 class RasterFn(torch.autograd.Function):
     """Composite one channel chunk.  `cfg` is the chunk's configuration (its D = the kernel width, depth mode set on
     the last chunk only); the projection outputs and the sorted tile lists come from the shared `st`.  The first chunk
@@ -374,53 +434,11 @@ class RasterFn(torch.autograd.Function):
             L.check(lib.d4gs_bin_sort(C.byref(dims), C.byref(pout), C.byref(isect), _stream()), "d4gs_bin_sort")
             raster(cap, max_hint)
 
-        key = _size_key(dev, S, cfg.N, W, H)
-        guess = None
-        if not st.binned and cfg.deferred_size_check:
-            capturing = torch.cuda.is_current_stream_capturing()
-            if not capturing:
-                _deferred_poll(key)  # raises if the previous render of this shape overflowed
-            guess = _guess_get(key)
         if st.binned:
             raster(st.n_isect, st.max_tile)
-        elif guess is not None:
-            # deferred check: launch at the guessed capacity, never wait.  The count travels to pinned memory behind
-            # the launches and is looked at by the next call (not under stream capture: a graph replays this shape).
-            launch(*guess)
-            if not capturing:
-                with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
-                    host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
-                if host_n is None:
-                    host_n = torch.empty(2, dtype=torch.int64).pin_memory()
-                host_n.copy_(st.proj_out["n_isect"], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                with _SIZE_LOCK:
-                    _DEFERRED.setdefault(key, []).append((host_n, ev, guess[0], guess[1]))
-            st.n_isect, st.max_tile, st.binned = guess[0], guess[1], True
-            st.raster = rst
-            _SIZE_STATS["calls"] += 1
         else:
-            # The list sizes live on the device.  Read them back through pinned memory; when a previous call of the same
-            # shape left a guess, launch binning + rasterization FIRST (sized by the guess, checked on the device) and
-            # wait for the counts afterwards, so the GPU never idles on the host round trip (70 us per render).
-            host_n = _pinned_counts(dev)
-            host_n.copy_(st.proj_out["n_isect"], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            guess = _guess_get(key) if cfg.optimistic_sizes else None
-            if guess is not None:
-                launch(*guess)
-            ev.synchronize()
-            n, max_tile = host_n.tolist()
-            if guess is None or n > guess[0] or (guess[1] > 0 and max_tile > guess[1]):
-                if guess is not None:
-                    _SIZE_STATS["relaunched"] += 1
-                launch(n, max_tile)
-            _SIZE_STATS["calls"] += 1
-            _guess_put(key, (n + n // 4 + 4096,
-                             _sort_class(max_tile)))
-            st.n_isect, st.max_tile, st.binned = n, max_tile, True
+            st.n_isect, st.max_tile = _sized_launch(cfg, dev, lambda: st.proj_out["n_isect"], launch)
+            st.binned = True
             st.raster = rst
         ctx.st, ctx.cfg, ctx.rst, ctx.ctab = st, cfg, rst, ctab
         return rst["render_colors"].view(S, H, W, cfg.NCH), rst["render_alphas"].unsqueeze(-1)
@@ -459,6 +477,125 @@ class RasterFn(torch.autograd.Function):
         L.check(lib.d4gs_raster_bwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), C.byref(rg), _stream()),
                 "d4gs_raster_bwd")
         return None, None, g["v_means2d"], g["v_conics"], g["v_depths"], g["v_opac_act"], g["v_ctab"], None
+
+
+class FrameFn(torch.autograd.Function):
+    """The whole path as ONE autograd node over the one-call C entry points (d4gs_forward / d4gs_backward):
+    leaves -> (blended [H,W,D'] | None, acc [H,W] | None, renders [S,H,W,D'], alphas [S,H,W]), all differentiable (the
+    reference puts losses on the blurry frame AND on the sub-sample images, trainer.py:575-618).  One workspace tensor,
+    one ctypes call each way - the staged ProjectFn / RasterFn / BlendFn chain costs ~30 allocations, five calls and three
+    Python autograd nodes per direction, which is what bounds small scenes (BASELINE cfg1) and the sharded step.  Bit-identical
+    to the staged chain (same kernels, same order).  `means2d` is not an autograd intermediate here: its gradient - the
+    densification side channel (flow3d/scene_model.py:456-461, trainer.py:975) - is deposited by the backward into
+    `st.xys_sink` (a list of S leaf tensors [1,N,2], see SceneModel.render) and kept as `st.v_means2d`."""
+
+    @staticmethod
+    def forward(ctx, st: State, blend_policy, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs,
+                viewmat, Kmat, background):
+        cfg = st.cfg
+        _need_gpu(means)
+        dev = means.device
+        S, N, H, W, NCH = cfg.S, cfg.N, cfg.height, cfg.width, cfg.NCH
+        f32 = dict(dtype=torch.float32, device=dev)
+        lib = L.lib()
+        st.proj_in = dict(means=_f32c(means), quats=_f32c(quats), scales=_f32c(scales), opacities=_f32c(opacities),
+                          colors=_f32c(colors), motion_coefs=_f32c(motion_coefs), rots=_f32c(rots),
+                          transls=_f32c(transls), times=_f32c(times), RTs=_f32c(RTs), viewmat=_f32c(viewmat),
+                          Kmat=_f32c(Kmat))
+        blended = blend_policy is not None
+        io = dict(blended=torch.empty(H, W, NCH, **f32) if blended else None, acc=torch.empty(H, W, **f32) if blended else None,
+                  renders=torch.empty(S, H, W, NCH, **f32), alphas=torch.empty(S, H, W, **f32),
+                  means2d=torch.empty(S, N, 2, **f32), radii=torch.empty(S, N, dtype=torch.int32, device=dev),
+                  n_isect=torch.empty(2, dtype=torch.int64, device=dev), background=_f32c(background))
+        dims = cfg.dims()
+        pin = L.fill(L.ProjIn(), **st.proj_in)
+        fio = L.fill(L.FrameIO(), **io)
+        pol = (C.c_int32 * NCH)(*blend_policy) if blended else None
+        if blended:
+            fio.policy = pol
+
+        def launch(cap, max_hint):
+            nbytes = lib.d4gs_frame_workspace_bytes(C.byref(dims), cap)
+            st.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            st.ws_ptr = (st.ws.data_ptr() + 255) & ~255
+            st.ws_bytes = nbytes
+            st.ws_cap = (cap, max_hint)  # the workspace layout follows the capacity: the backward must carve it the same way
+            L.check(lib.d4gs_forward(C.byref(dims), C.byref(pin), C.byref(fio), C.c_void_p(st.ws_ptr), nbytes, cap, max_hint,
+                                     _stream()), "d4gs_forward")
+
+        st.n_isect, st.max_tile = _sized_launch(cfg, dev, lambda: io["n_isect"], launch, count_needs_launch=True)
+        st.binned = True
+        st.frame_io, st.policy = io, pol
+        ctx.st = st
+        ctx.save_for_backward(*[st.proj_in[k] for k in _PROJ_IN])  # version-checked, like ProjectFn
+        ctx.needs = [t is not None and t.requires_grad for t in
+                     (means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat)]
+        ra = (io["renders"].view(S, H, W, NCH), io["alphas"].view(S, H, W))
+        if blended:
+            return (io["blended"].view(H, W, NCH), io["acc"].view(H, W), *ra)
+        return (None, None, *ra)
+
+    @staticmethod
+    def backward(ctx, v_blended, v_acc, v_renders, v_alphas):
+        st: State = ctx.st
+        cfg, io = st.cfg, st.frame_io
+        dev = io["renders"].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        lib = L.lib()
+        dims = cfg.dims()
+        pi = dict(zip(_PROJ_IN, ctx.saved_tensors))
+        dyn = cfg.G > 0
+        arena = cfg.grad_arena or {}
+        blended = io["blended"] is not None
+        c32 = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        v_blended, v_acc, v_renders, v_alphas = c32(v_blended), c32(v_acc), c32(v_renders), c32(v_alphas)
+        if not blended and v_renders is None:
+            v_renders = torch.zeros_like(io["renders"])
+        if blended and v_blended is None and v_acc is None and v_renders is None and v_alphas is None:
+            v_blended = torch.zeros_like(io["blended"])
+
+        def buf(name, *shape):
+            t = arena.get(name)
+            if t is not None and t.shape == torch.Size(shape) and t.dtype == torch.float32 and t.is_contiguous():
+                return t.view(shape)
+            return torch.empty(*shape, **f32)
+
+        g = dict(
+            v_means=buf("means", cfg.N, 3), v_quats=buf("quats", cfg.N, 4), v_scales=buf("scales", cfg.N, 3),
+            v_opacities=buf("opacities", cfg.N), v_colors=buf("colors", cfg.N, cfg.D),
+            v_motion_coefs=buf("motion_coefs", cfg.G, cfg.K) if dyn else None,
+            v_rots=buf("rots", cfg.K, cfg.T, 6) if dyn else None, v_transls=buf("transls", cfg.K, cfg.T, 3) if dyn else None,
+            v_times=buf("times", cfg.S) if dyn else None, v_RTs=buf("RTs", cfg.S, 3, 4) if pi["RTs"] is not None else None,
+            v_viewmat=buf("viewmat", 4, 4), partials=None)
+        v_m2d = torch.empty(cfg.S, cfg.N, 2, **f32)
+        fg = L.FrameGrads()
+        fg.v_blended, fg.v_acc, fg.v_renders, fg.v_alphas = L.ptr(v_blended), L.ptr(v_acc), L.ptr(v_renders), L.ptr(v_alphas)
+        fg.v_means2d = L.ptr(v_m2d)
+        fg.row_mode = {"auto": L.ROWS_AUTO, "dense": L.ROWS_DENSE, "sparse": L.ROWS_SPARSE}[BWD_ROWS]
+        if cfg.control_stats is not None:
+            cs = _check_stats(cfg.control_stats, cfg.N)
+            fg.stats_grad_norm_acc, fg.stats_vis_count = L.ptr(cs["xys_grad_norm_acc"]), L.ptr(cs["vis_count"])
+            fg.stats_max_radii = L.ptr(cs["max_radii"])
+            fg.stats_batch_size, fg.stats_update_max_radii = int(cs["batch_size"]), int(bool(cs.get("update_max_radii", False)))
+        fio = L.fill(L.FrameIO(), **io)
+        if blended:
+            fio.policy = st.policy
+        L.check(lib.d4gs_backward(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pi)), C.byref(fio), C.byref(fg),
+                                  C.byref(L.fill(L.LeafGrads(), **g)), C.c_void_p(st.ws_ptr), st.ws_bytes, st.ws_cap[0], st.ws_cap[1],
+                                  _stream()), "d4gs_backward")
+        st.v_means2d = v_m2d
+        if st.xys_sink is not None:  # the `_current_xys[i].grad` side channel
+            for s, x in enumerate(st.xys_sink):
+                x.grad = v_m2d[s:s + 1]
+        outs = [g["v_means"], g["v_quats"], g["v_scales"], g["v_opacities"], g["v_colors"], g["v_motion_coefs"],
+                g["v_rots"], g["v_transls"], g["v_times"], g["v_RTs"], g["v_viewmat"]]
+        outs = [x if need else None for x, need in zip(outs, ctx.needs)]
+        return (None, None, *outs, None, None)
+
+
+def frame_supported(cfg: RenderCfg) -> bool:
+    """One kernel width, no channel chunking: what the one-call path covers."""
+    return cfg.N > 0 and cfg.D in SUPPORTED_D
 
 
 class PosesFn(torch.autograd.Function):
@@ -515,7 +652,10 @@ class PosesFn(torch.autograd.Function):
         c = lambda t: None if t is None else t.to(torch.float32).contiguous()
         if not dyn:
             v_tfs = None
-        vo = L.fill(L.Poses(), means=c(v_means), quats=c(v_quats) if pin["quats"] is not None else None, transforms=c(v_tfs))
+        # (keep the contiguous copies referenced until the call below has been enqueued: a temporary that dies earlier hands
+        # its block back to the caching allocator, and the very next torch.empty - the gradient buffers - would alias it)
+        vin = dict(means=c(v_means), quats=c(v_quats) if pin["quats"] is not None else None, transforms=c(v_tfs))
+        vo = L.fill(L.Poses(), **vin)
         vo.g_major = int(ctx.g_major)
         g = dict(v_means=torch.empty(cfg.N, 3, **f32), v_quats=torch.empty(cfg.N, 4, **f32) if vo.quats else None,
                  v_scales=None, v_opacities=None, v_colors=None,
@@ -528,6 +668,7 @@ class PosesFn(torch.autograd.Function):
                  partials=torch.empty(lib.d4gs_bwd_partials_elems(C.byref(dims)), **f32))
         L.check(lib.d4gs_poses_bwd(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pin)), C.byref(vo),
                                    C.byref(L.fill(L.LeafGrads(), **g)), _stream()), "d4gs_poses_bwd")
+        del vin
         outs = [g["v_means"], g["v_quats"], g["v_motion_coefs"], g["v_rots"], g["v_transls"], g["v_times"], g["v_RTs"]]
         return (*(x if need else None for x, need in zip(outs, ctx.needs)), None, None, None)
 

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .engine import RenderCfg, _stream, render_instances
+from .engine import FrameFn, RenderCfg, State, _stream, frame_supported, render_instances
 
 POLICY_MEAN, POLICY_MAX, POLICY_MIN = 0, 1, 2
 
@@ -84,9 +84,12 @@ def render_exposure(
     grad_arena: dict | None = None,
     control_stats: dict | None = None,
     deferred_size_check: bool = False,
+    fused: bool = False,
 ):
     """-> dict(renders [S,H,W,D'], alphas [S,H,W,1], blended [H,W,D'] | None, acc [H,W] | None,
-               means2d [S,N,2], radii [S,N], state)."""
+               means2d [S,N,2], radii [S,N], state).
+    fused=True takes the one-call path (engine.FrameFn) when the channel count needs no chunking: one autograd node, every
+    output differentiable; `means2d` is then a plain tensor whose gradient lands in state.xys_sink / state.v_means2d."""
     N = means.shape[0]
     G = 0 if motion_coefs is None else motion_coefs.shape[0]
     S = 1 if times is None else times.shape[0]
@@ -98,6 +101,15 @@ def render_exposure(
                     depth_mode=L.DEPTH_ED if return_depth else L.DEPTH_NONE, flags=flags, n_sigmoid=n_sigmoid,
                     exact_cull=exact_cull, grad_arena=grad_arena, control_stats=control_stats,
                     deferred_size_check=deferred_size_check)
+    if fused and frame_supported(cfg):
+        # ONE autograd node over d4gs_forward / d4gs_backward: same kernels and bits as the staged chain below, a fraction
+        # of its host work.  `means2d` is then a plain tensor; its gradient goes to st.xys_sink / st.v_means2d.
+        st = State(cfg)
+        pol = (reference_policy(cfg.NCH) if policy is None else list(policy)) if blend else None
+        bl, acc, rc, ra = FrameFn.apply(st, pol, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs,
+                                        w2c, Kmat, background)
+        io = st.frame_io
+        return dict(renders=rc, alphas=ra.unsqueeze(-1), means2d=io["means2d"], radii=io["radii"], state=st, blended=bl, acc=acc)
     rc, ra, means2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors, motion_coefs, rots,
                                                   transls, times, RTs, w2c, Kmat, background)
     out = dict(renders=rc, alphas=ra, means2d=means2d, radii=radii, state=st, blended=None, acc=None)

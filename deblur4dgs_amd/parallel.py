@@ -5,14 +5,15 @@ constrained only by "the sharded result equals the single-GPU result":
 
 * exposure sharding (BASELINE config 4): the S sub-samples of ONE blurry frame are independent given replicated
   leaf parameters (flow3d/scene_model.py:323-384); rank r renders {s : s % P == r}.  The only coupling is the blend
-  (scene_model.py:386-397).  Default (`GatherBlendFn`, needs S % P == 0): an all-gather of the ranks' sub-sample
-  colour images [S/P,H,W,D'] and one of their alphas put the whole S-stack on every rank, which then runs the same HIP blend kernels as the
-  single-GPU path (`k_blend_fwd/bwd`) - the blended image is BITWISE the single-GPU image (same summation order),
-  the max / min channels and their winners need no extra collective, the backward keeps the slice of the stack
-  gradient that belongs to the rank's own sub-samples (the loss is evaluated redundantly, so no reduction), and the
-  per-sub-sample stack the trainer's pairwise exposure losses read (flow3d/trainer.py:599-618) is there for free.
-  Ragged S falls back to `ShardedBlendFn`: SUM all-reduce of [H,W,D'+1] + MAX all-reduce of the policy channels
-  (min packed as -x) forward, MIN all-reduce of the winning sub-sample backward.
+  (scene_model.py:386-397).  Default (`ShardedBlendFn`, any S): the blended image is REDUCED - SUM all-reduce of
+  [H,W,D'+1] + MAX all-reduce of the policy channels (min packed as -x) forward (2.9 MB on cfg4), MIN
+  all-reduce of the winning sub-sample backward - and equals the single-GPU blend up to fp32 summation order.
+  When the caller needs the per-sub-sample stack (`need_stack=True`: the trainer's pairwise exposure losses,
+  flow3d/trainer.py:599-618; needs S % P == 0) `GatherBlendFn` all-gathers the ranks' sub-sample colour images
+  [S/P,H,W,D'] and alphas (23.6 MB on cfg4) and runs the same HIP blend kernels as the single-GPU path
+  (`k_blend_fwd/bwd`) on the full stack: the blended image is then BITWISE the single-GPU image (same summation
+  order), the max / min channels and their winners need no extra collective, and the backward keeps the slice of the
+  stack gradient that belongs to the rank's own sub-samples (the loss is evaluated redundantly, so no reduction).
   Then the leaf gradients: ONE flat buffer, all-reduced in two pieces - the per-Gaussian leaves (24 MB on cfg2) as
   soon as the projection backward has written them (async on RCCL's stream, overlapping the rest of autograd: the
   MoveModel backward and the host-side launch work), the small shared leaves at the end.
@@ -33,14 +34,54 @@ def owned_subsamples(S: int, world: int, rank: int) -> list[int]:
     return [s for s in range(S) if s % world == rank]
 
 
+def _shard_desc(Sl, S, s_ids, Cn, n_pixels, policy):
+    import ctypes as C
+
+    from . import _lib as L
+
+    pol = (C.c_int32 * Cn)(*policy)
+    first = s_ids[0] if s_ids else 0
+    stride = (s_ids[1] - s_ids[0]) if len(s_ids) > 1 else 1
+    assert all(s == first + j * stride for j, s in enumerate(s_ids)), "owned sub-samples must be an arithmetic sequence"
+    return L.ShardBlend(S, Sl, first, stride, Cn, n_pixels, pol), pol
+
+
 class ShardedBlendFn(torch.autograd.Function):
-    """Distributed counterpart of exposure.BlendFn.  `renders` holds only this rank's sub-samples."""
+    """Distributed counterpart of exposure.BlendFn: `renders` holds only this rank's sub-samples, the blended image is
+    REDUCED over the ranks (SUM of colours + alpha, MAX of the policy channels; MIN of the winning sub-sample backward).
+    Device tensors: the arithmetic is the HIP kernels d4gs_blend_shard_* (csrc/blend.hip), torch.distributed only moves
+    the three small buffers.  CPU tensors (the gloo tests of the N > 1 logic): the same steps restated in torch."""
 
     @staticmethod
     def forward(ctx, renders, alphas, s_ids, S, policy, group):
         # renders [S_loc,H,W,C], alphas [S_loc,H,W], s_ids: global sub-sample index of each local slice
         Sl, H, W, Cn = renders.shape
         dev = renders.device
+        if renders.is_cuda:
+            import ctypes as C
+
+            from . import _lib as L
+            from .engine import _stream
+
+            renders, alphas = renders.to(torch.float32).contiguous(), alphas.to(torch.float32).contiguous()
+            desc, _keep = _shard_desc(Sl, S, list(s_ids), Cn, H * W, policy)
+            npol = sum(1 for p in policy if p != POLICY_MEAN)
+            part = torch.empty(H, W, Cn + 1, dtype=torch.float32, device=dev)
+            cand = torch.empty(H, W, max(npol, 1), dtype=torch.float32, device=dev)
+            lib = L.lib()
+            L.check(lib.d4gs_blend_shard_partial_fwd(C.byref(desc), L.ptr(renders), L.ptr(alphas), L.ptr(part), L.ptr(cand),
+                                                     _stream()), "d4gs_blend_shard_partial_fwd")
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+            if npol and S > 1:
+                dist.all_reduce(cand, op=dist.ReduceOp.MAX, group=group)
+            out = torch.empty(H, W, Cn, dtype=torch.float32, device=dev)
+            acc = torch.empty(H, W, dtype=torch.float32, device=dev)
+            L.check(lib.d4gs_blend_shard_finish_fwd(C.byref(desc), L.ptr(part), L.ptr(cand), L.ptr(out), L.ptr(acc), _stream()),
+                    "d4gs_blend_shard_finish_fwd")
+            ctx.save_for_backward(renders, out)
+            ctx.meta = (list(s_ids), S, list(policy), group)
+            ctx.npol = npol
+            return out, acc
         summed = torch.cat([renders.sum(0), alphas.sum(0)[..., None]], -1) if Sl > 0 else \
             torch.zeros(H, W, Cn + 1, device=dev, dtype=renders.dtype)
         dist.all_reduce(summed, op=dist.ReduceOp.SUM, group=group)
@@ -72,6 +113,26 @@ class ShardedBlendFn(torch.autograd.Function):
         Sl, H, W, Cn = renders.shape
         dev = renders.device
         v_out = torch.zeros_like(out) if v_out is None else v_out
+        if renders.is_cuda:
+            import ctypes as C
+
+            from . import _lib as L
+            from .engine import _stream
+
+            desc, _keep = _shard_desc(Sl, S, s_ids, Cn, H * W, policy)
+            lib = L.lib()
+            win = torch.empty(H, W, max(ctx.npol, 1), dtype=torch.int32, device=dev)
+            if ctx.npol and S > 1:
+                L.check(lib.d4gs_blend_shard_winner(C.byref(desc), L.ptr(renders), L.ptr(out), L.ptr(win), _stream()),
+                        "d4gs_blend_shard_winner")
+                dist.all_reduce(win, op=dist.ReduceOp.MIN, group=group)
+            v_out = v_out.to(torch.float32).contiguous()
+            v_acc = None if v_acc is None else v_acc.to(torch.float32).contiguous()
+            v_r = torch.empty_like(renders)
+            v_a = torch.empty(Sl, H, W, dtype=torch.float32, device=dev)
+            L.check(lib.d4gs_blend_shard_bwd(C.byref(desc), L.ptr(v_out), L.ptr(v_acc), L.ptr(win), L.ptr(v_r), L.ptr(v_a),
+                                             _stream()), "d4gs_blend_shard_bwd")
+            return v_r, v_a, None, None, None, None
         v_r = (v_out / S).expand(Sl, H, W, Cn).clone() if S > 1 else v_out.expand(Sl, H, W, Cn).clone()
         pol_ch = ctx.pol_ch
         if pol_ch and S > 1 and Sl > 0:
@@ -221,9 +282,16 @@ class FlatGradAllReduce:
 class ShardedExposure:
     """Driver used by bench.py and the training-style callers: one step = fwd + bwd + gradient all-reduce."""
 
-    def __init__(self, world: int, rank: int, mode: str = "exposure", group=None):
+    def __init__(self, world: int, rank: int, mode: str = "exposure", group=None, need_stack: bool = False):
         assert mode in ("exposure", "views")
         self.world, self.rank, self.mode, self.group = world, rank, mode, group
+        # exposure sharding, forward collective: need_stack=False (default) REDUCES the blended image - SUM of [H,W,D'+1]
+        # + MAX of the policy channels, 2.9 MB on cfg4 (SURVEY 8e) - equal to the single-GPU blend up to fp32 summation
+        # order (<= 2e-6 * max|value|, tests/test_parallel_gloo.py); need_stack=True ALL-GATHERS the per-sub-sample stack
+        # (23.6 MB on cfg4) and blends it with the single-GPU kernels: bitwise equal, and the stack the reference's
+        # pairwise exposure losses read (flow3d/trainer.py:599-618) is present on every rank
+        self.need_stack = need_stack
+        self.fused = True  # renders go through the one-call autograd node (engine.FrameFn); False: the staged chain
         self.reducer = None
         self.deferred_size_check = False  # True: no render waits for its list sizes on the host (engine.RenderCfg) - needed
         #                                   to capture the step, collectives included, in a HIP graph
@@ -244,7 +312,7 @@ class ShardedExposure:
                                   leaves["colors"], 3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                                   leaves["times"], leaves["RTs"], leaves["viewmat"], Kmat, W, H, background=background,
                                   return_depth=True, grad_arena=self.reducer.views,
-                                  deferred_size_check=self.deferred_size_check)
+                                  deferred_size_check=self.deferred_size_check, fused=self.fused)
             loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
             # data-parallel mean of the per-view gradients: the 1 / world factor rides on the loss, so the SUM
             # all-reduce needs no 24 MB division pass afterwards
@@ -258,14 +326,14 @@ class ShardedExposure:
                               3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                               leaves["times"][sel], leaves["RTs"][sel],
                               leaves["viewmat"], Kmat, W, H, background=background, return_depth=True, blend=False,
-                              grad_arena=self.reducer.views, deferred_size_check=self.deferred_size_check)
+                              grad_arena=self.reducer.views, deferred_size_check=self.deferred_size_check, fused=self.fused)
         pol = reference_policy(res["renders"].shape[-1])
-        if S % self.world == 0:  # one all-gather, then the single-GPU blend kernels on the full stack (bitwise equal)
+        if self.need_stack and S % self.world == 0:  # one all-gather, then the single-GPU blend kernels on the full stack
             from .exposure import BlendFn
 
             blended, acc, _stack_r, _stack_a = GatherBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), S, pol,
                                                                    self.group, BlendFn.apply)
-        else:
+        else:  # reduce: SUM + MAX forward, MIN of the winning sub-sample backward (also the ragged-S path)
             blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), own, S, pol, self.group)
         loss = torch.dot(blended.reshape(-1), wimg.reshape(-1)) + torch.dot(acc.reshape(-1), wacc.reshape(-1))
         self.reducer.arm(leaves)

@@ -149,6 +149,8 @@ class SceneModel(nn.Module):
         self.move_model = MoveModel(num_fg=self.num_fg_gaussians, camera_mode="linear").to(Ks.device)
         self.inplace_blend_quirk = True  # exposure_imgs[-1] is the blended frame (scene_model.py:391,486)
         self._stats_sink = None
+        self.fused = True  # one autograd node over d4gs_forward / d4gs_backward where the channel count allows it (same bits
+        #                    as the staged chain, a fraction of the host work); False: always the staged chain
         self.deferred_size_check = False  # True: renders never wait for the device-side intersection count (engine
         #                                   RenderCfg.deferred_size_check; call engine.check_deferred() once per step)
 
@@ -345,20 +347,23 @@ class SceneModel(nn.Module):
             times_s if G > 0 else None, RTs_s, w2cs[0], Ks[0], W, H, background=bg_color[0], return_depth=return_depth,
             policy=None, blend=True,
             control_stats=self._sink_for(N) if (which == "all" and filter_mask is None) else None,
-            deferred_size_check=self.deferred_size_check)
+            deferred_size_check=self.deferred_size_check, fused=self.fused)
         blended = res["blended"][None]  # [1,H,W,D']
         renders = res["renders"]
 
         # side channels for densification (scene_model.py:456-461; consumed at trainer.py:967-989)
         m2d = res["means2d"]
-        if m2d.requires_grad:
+        one_call = bool(res["state"].frame_io)  # engine.FrameFn: one autograd node, means2d is not an intermediate
+        if m2d.requires_grad or (one_call and torch.is_grad_enabled() and blended.requires_grad):
             xys = [m2d.detach()[s:s + 1].requires_grad_() for s in range(S)]
+            if one_call:
+                res["state"].xys_sink = xys  # the backward deposits d loss / d means2d there
+            else:
+                def _deposit(g, xys=xys):
+                    for s, x in enumerate(xys):
+                        x.grad = g[s:s + 1]
 
-            def _deposit(g, xys=xys):
-                for s, x in enumerate(xys):
-                    x.grad = g[s:s + 1]
-
-            m2d.register_hook(_deposit)
+                m2d.register_hook(_deposit)
             self._current_xys = xys
             self._current_radii = [res["radii"][s:s + 1] for s in range(S)]
             self._current_img_wh = img_wh

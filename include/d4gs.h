@@ -352,6 +352,64 @@ int d4gs_blend_bwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy
                    const float *out, const float *v_out, const float *v_acc, float *v_renders /* [S,P,C] */,
                    float *v_alphas /* [S,P] */, void *stream);
 
+/* One call each way: d4gs_forward = d4gs_project_fwd + d4gs_bin_sort + d4gs_raster_fwd (+ d4gs_blend_fwd when
+ * io->blended != NULL), d4gs_backward = (d4gs_blend_bwd +) d4gs_raster_bwd + d4gs_project_bwd.  Same kernels, same order:
+ * bit-identical to the staged calls.  Every buffer that only lives between / inside the two calls sits in ONE caller-provided
+ * workspace (256-byte aligned, d4gs_frame_workspace_bytes(dims, isect_capacity) bytes; the forward's part of it must reach the
+ * backward untouched); what the caller reads is in D4gsFrameIO.  `isect_capacity` / `max_tile_hint` are D4gsIsect.n_isect /
+ * .max_tile_count: a guess the kernels check on the device - read io->n_isect afterwards and call again if it did not fit.
+ * The backward takes any of v_blended, v_acc, v_renders, v_alphas when io->blended was given (losses on the blurry frame and
+ * on the per-sub-sample images, flow3d/trainer.py:575-618), else v_renders [+ v_alphas]; a caller that needs `means2d` as an
+ * autograd intermediate or renders more than 16 colour channels uses the staged entry points. */
+typedef struct D4gsFrameIO {
+  float *blended;          /* [H,W,D+depth] or NULL: no blend */
+  float *acc;              /* [H,W] (with blended) */
+  float *renders;          /* [S,H,W,D+depth] */
+  float *alphas;           /* [S,H,W] */
+  float *means2d;          /* [S,N,2] */
+  int32_t *radii;          /* [S,N] */
+  int64_t *n_isect;        /* [2] device: {intersections, longest tile list} */
+  const float *background; /* [D] or NULL */
+  const int32_t *policy;   /* [host] [D+depth] blend policy per channel (0 mean, 1 max, 2 min) or NULL = all mean */
+} D4gsFrameIO;
+typedef struct D4gsFrameGrads {
+  const float *v_blended, *v_acc;     /* [H,W,D+depth], [H,W] or NULL */
+  const float *v_renders, *v_alphas;  /* [S,H,W,D+depth], [S,H,W] or NULL */
+  float *v_means2d;                   /* [S,N,2] out: the means2d.grad contract (trainer.py:975) */
+  float *stats_grad_norm_acc;         /* fused densification statistics, as in D4gsRasterGrads; NULL = off */
+  int64_t *stats_vis_count;
+  float *stats_max_radii;
+  int32_t stats_batch_size, stats_update_max_radii, row_mode;
+} D4gsFrameGrads;
+size_t d4gs_frame_workspace_bytes(const D4gsDims *dims, int64_t isect_capacity);
+int d4gs_forward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, void *workspace, size_t ws_bytes,
+                 int64_t isect_capacity, int64_t max_tile_hint, void *stream);
+int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, const D4gsFrameGrads *g,
+                  const D4gsLeafGrads *leaf /* .partials is ignored: it lives in the workspace */, void *workspace,
+                  size_t ws_bytes, int64_t isect_capacity, int64_t max_tile_hint, void *stream);
+
+/* Exposure sharding (one process per GPU): the same blend when this process holds only the sub-samples
+ * s_first + j * s_stride, j < S_local, of the S_total.  Collectives stay with the caller (RCCL through torch.distributed):
+ *   forward : partial_fwd -> all-reduce SUM of part [P,C+1] (colours + alpha) and MAX of cand [P,npol] (the max / min
+ *             policy channels in ascending channel order, min packed as -x; -inf where this rank has no candidate) -> finish_fwd;
+ *   backward: winner (lowest own s <= S_total-2 whose raw value equals the blended one, else S_total) -> all-reduce MIN ->
+ *             bwd.  The mean channels need no collective backward (the loss is evaluated on every rank).
+ * Equals d4gs_blend_fwd/bwd on the full stack up to the order of the S-term sums. */
+typedef struct D4gsShardBlend {
+  int32_t S_total, S_local, s_first, s_stride, C;
+  int64_t n_pixels;
+  const int32_t *policy; /* [host] [C] */
+} D4gsShardBlend;
+int d4gs_blend_shard_partial_fwd(const D4gsShardBlend *b, const float *renders /* [S_local,P,C] */,
+                                 const float *alphas /* [S_local,P] */, float *part /* [P,C+1] */, float *cand /* [P,npol] */,
+                                 void *stream);
+int d4gs_blend_shard_finish_fwd(const D4gsShardBlend *b, const float *part, const float *cand, float *out /* [P,C] */,
+                                float *acc /* [P] */, void *stream);
+int d4gs_blend_shard_winner(const D4gsShardBlend *b, const float *renders, const float *out, int32_t *win /* [P,npol] */,
+                            void *stream);
+int d4gs_blend_shard_bwd(const D4gsShardBlend *b, const float *v_out, const float *v_acc /* or NULL */, const int32_t *win,
+                         float *v_renders /* [S_local,P,C] */, float *v_alphas /* [S_local,P] */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

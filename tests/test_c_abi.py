@@ -117,3 +117,26 @@ def test_query_sizes_is_a_pure_host_call(lib):
     assert z.scan_ws == lib.d4gs_scan_ws_elems(SN) and z.bwd_partials == lib.d4gs_bwd_partials_elems(C.byref(d))
     bad = L.Dims(N=10, G=20, K=1, T=1, S=1, D=3, width=16, height=16)
     assert lib.d4gs_query_sizes(C.byref(bad), C.byref(z)) == -1 and lib.d4gs_query_sizes(C.byref(d), None) == -1
+
+
+def test_one_call_entry_points_validate_before_any_hip_call(lib):
+    from deblur4dgs_amd import _lib as L
+
+    lib.d4gs_last_error.restype = C.c_char_p
+    lib.d4gs_frame_workspace_bytes.restype = C.c_size_t
+    lib.d4gs_frame_workspace_bytes.argtypes = [C.POINTER(L.Dims), C.c_int64]
+    d = L.Dims(N=1000, G=0, K=0, T=0, S=2, D=3, width=64, height=48, depth_mode=1)
+    small, big = lib.d4gs_frame_workspace_bytes(C.byref(d), 0), lib.d4gs_frame_workspace_bytes(C.byref(d), 100000)
+    assert 0 < small < big and small % 256 == 0 and big - small >= 100000 * (8 + 12 + 4 * 10)  # keys, ids, gradient rows
+    assert lib.d4gs_frame_workspace_bytes(C.byref(L.Dims(N=-1, S=1, D=3, width=8, height=8)), 0) == 0
+    lib.d4gs_forward.argtypes = [C.POINTER(L.Dims), C.POINTER(L.ProjIn), C.POINTER(L.FrameIO), C.c_void_p, C.c_size_t, C.c_int64,
+                                 C.c_int64, C.c_void_p]
+    fake = 0x10000
+    pin = L.ProjIn(**{n: fake for n, _ in L.ProjIn._fields_})
+    io = L.FrameIO(**{n: fake for n in ("renders", "alphas", "means2d", "radii", "n_isect")})
+    assert lib.d4gs_forward(C.byref(d), C.byref(pin), C.byref(io), C.c_void_p(fake), small - 1, 0, 0, None) == -3  # D4GS_ECAPACITY
+    assert b"workspace" in lib.d4gs_last_error()
+    assert lib.d4gs_forward(C.byref(d), C.byref(pin), C.byref(io), C.c_void_p(fake + 8), small, 0, 0, None) == -1
+    assert b"aligned" in lib.d4gs_last_error()
+    io2 = L.FrameIO(**{n: fake for n in ("renders", "alphas", "means2d", "radii")})  # n_isect missing
+    assert lib.d4gs_forward(C.byref(d), C.byref(pin), C.byref(io2), C.c_void_p(fake), small, 0, 0, None) == -1

@@ -1,0 +1,114 @@
+"""The one-call entry points d4gs_forward / d4gs_backward behind ONE autograd node (engine.FrameFn) against the
+staged chain (d4gs_project_fwd -> d4gs_bin_sort -> d4gs_raster_fwd -> d4gs_blend_fwd and back; ProjectFn / RasterFn /
+BlendFn): the same kernels in the same order, so every output and every gradient must be BITWISE equal - which puts the
+one-call path under all the oracle parity the staged chain has."""
+import pytest
+import torch
+
+from deblur4dgs_amd.synth import make_scene
+
+pytestmark = pytest.mark.gpu
+NAMES = ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls", "times", "RTs", "viewmat")
+
+
+def _leaves(sc, dev):
+    return {k: (sc[k].to(dev).clone().requires_grad_() if k in sc and sc[k] is not None else None) for k in NAMES}
+
+
+def _render(L, K, W, H, fused, blend=True, D=3, **kw):
+    from deblur4dgs_amd.exposure import render_exposure
+
+    cols = L["colors"] if D == 3 else torch.cat([L["colors"], L["means"].repeat(1, 5)], -1)[:, :D]
+    return render_exposure(L["means"], L["quats"], L["scales"], L["opacities"], cols, 3, L["motion_coefs"], L["rots"],
+                           L["transls"], L["times"], L["RTs"], L["viewmat"], K, W, H, background=torch.linspace(0.2, 0.9, D).to(K.device),
+                           return_depth=True, blend=blend, fused=fused, **kw)
+
+
+@pytest.mark.parametrize("N,G,K_,S,W,H,D", [(5000, 3000, 4, 3, 160, 96, 3), (800, 0, 1, 1, 64, 48, 3), (3000, 3000, 12, 5, 96, 64, 16)])
+def test_one_call_path_equals_the_staged_chain_bitwise(N, G, K_, S, W, H, D):
+    dev = torch.device("cuda:0")
+    sc = make_scene(N, G, max(K_, 1), S, W, H, seed=31)
+    K = sc["K"].to(dev)
+    g = torch.Generator().manual_seed(7)
+    wb, wa = torch.randn(H, W, D + 1, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
+    ws, wsa = torch.randn(S, H, W, D + 1, generator=g).to(dev), torch.randn(S, H, W, 1, generator=g).to(dev)
+    out = {}
+    for fused in (False, True):
+        L = _leaves(sc, dev)
+        if G == 0:
+            L["motion_coefs"] = L["rots"] = L["transls"] = L["times"] = None  # a static scene (BASELINE cfg1's shape)
+        r = _render(L, K, W, H, fused, D=D)
+        assert bool(r["state"].frame_io) == fused
+        # losses on the blurry frame, its accumulation AND the per-sub-sample images (flow3d/trainer.py:575-618)
+        loss = (r["blended"] * wb).sum() + (r["acc"] * wa).sum() + (r["renders"] * ws).sum() + (r["alphas"] * wsa).sum()
+        xys = None
+        if fused:
+            xys = [r["means2d"][s:s + 1].detach().requires_grad_() for s in range(S)]
+            r["state"].xys_sink = xys
+        else:
+            r["means2d"].retain_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        m2g = torch.cat([x.grad for x in xys], 0) if fused else r["means2d"].grad
+        out[fused] = dict(blended=r["blended"], acc=r["acc"], renders=r["renders"], alphas=r["alphas"], means2d=r["means2d"],
+                          radii=r["radii"], m2g=m2g, **{f"g_{k}": v.grad for k, v in L.items() if v is not None})
+    for k, a in out[False].items():
+        b = out[True][k]
+        assert a is not None and b is not None and torch.equal(a.detach(), b.detach()), k
+    assert float(out[True]["g_means"].abs().max()) > 0 and float(out[True]["m2g"].abs().max()) > 0
+
+
+def test_one_call_path_unblended_and_size_protocol():
+    """blend=False (what exposure sharding renders), a cold size guess (the counting call), a warm one, and an overflowing
+    deferred one - the protocol is the staged chain's."""
+    from deblur4dgs_amd import engine
+
+    dev = torch.device("cuda:0")
+    N, G, K_, S, W, H = 4000, 2500, 3, 2, 128, 80
+    sc = make_scene(N, G, K_, S, W, H, seed=33)
+    K = sc["K"].to(dev)
+    w = torch.randn(S, H, W, 4, generator=torch.Generator().manual_seed(1)).to(dev)
+    ref = _leaves(sc, dev)
+    r0 = _render(ref, K, W, H, False, blend=False)
+    (r0["renders"] * w).sum().backward()
+    engine.check_deferred()
+    engine._SIZE_GUESS.clear()
+    for it in range(2):  # cold (counting call + exact launch), then warm (one launch, checked afterwards)
+        got = _leaves(sc, dev)
+        r1 = _render(got, K, W, H, True, blend=False)
+        assert r1["blended"] is None
+        (r1["renders"] * w).sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(r0["renders"], r1["renders"]) and all(torch.equal(ref[k].grad, got[k].grad) for k in NAMES), it
+    big = _leaves(sc, dev)
+    with torch.no_grad():
+        big["scales"] += 2.0
+    rb = _render(big, K, W, H, True, blend=False, deferred_size_check=True)  # the guess is far too small
+    (rb["renders"] * w).sum().backward()
+    with pytest.raises(RuntimeError, match="INVALID"):
+        engine.check_deferred()
+    torch.cuda.synchronize()
+    assert float(big["means"].grad.abs().sum()) == 0.0  # an overflowed render's gradients are zeros
+
+
+def test_scene_model_uses_the_one_call_path_and_keeps_the_side_channels():
+    from tests.test_gpu_scene_model import _build
+
+    dev = torch.device("cuda:0")
+    N, G, K_, W, H = 900, 500, 4, 64, 48
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(123)  # (MoveModel's random initialisation happens inside _build, before its own seeding)
+        model, sc = _build(N, G, K_, W, H, 17, dev)
+        model.fused = fused
+        out = model.render(3.0, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H), return_depth=True, return_mask=True,
+                           mode="blury")
+        loss = out["img"].square().sum() + out["depth"].sum() + out["exposure_imgs"][2].sum() + out["acc"].sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        res[fused] = dict(img=out["img"], depth=out["depth"], exp=out["exposure_imgs"],
+                          xys=torch.cat([x.grad for x in model._current_xys], 0), radii=torch.cat(model._current_radii, 0),
+                          **{n: p.grad for n, p in model.named_parameters() if p.grad is not None})
+    assert set(res[True]) == set(res[False]) and "move_model.RT_head0.2.bias" in res[True]
+    for k in res[True]:
+        assert torch.equal(res[True][k].detach(), res[False][k].detach()), k

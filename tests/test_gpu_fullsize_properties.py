@@ -133,11 +133,11 @@ def test_subsamples_in_two_calls_equal_one_call(scene):
 def test_full_size_subsample_matches_scalar_c_oracle(scene):
     """One exposure sub-sample of cfg2 (300 k Gaussians, 288x512) and of cfg3 (720x1280) against the scalar C
     restatement in fp64 - the only oracle fast enough at this size: images and all per-Gaussian gradients of the
-    rasterizer stage.  (cfg5's single sub-sample is the same code path as cfg3's with 3.3x the splats: properties only.)"""
+    rasterizer stage.  cfg5 (1 M Gaussians, K = 12) takes the windowed comparison below, through the FUSED path."""
     import numpy as np
 
     if scene["name"] == "cfg5":
-        pytest.skip("cfg5: property suite only (the scalar-C oracle needs minutes per sub-sample at 1 M x 720p)")
+        return _cfg5_window_vs_oracle(scene)
     S, W, H = scene["S"], scene["W"], scene["H"]
     case = f"{scene['name']} sub-sample vs scalar-C fp64"
 
@@ -177,3 +177,78 @@ def test_full_size_subsample_matches_scalar_c_oracle(scene):
     check(case, "render_alphas", ra[0].cpu(), al, 1e-4, 1e-4)
     for name in ("means", "quats", "scales", "opac", "colors"):
         check(case, name, t[name].grad.cpu(), ref[name], 1e-4, 1e-4)
+
+
+def _cfg5_window_vs_oracle(scene):
+    """cfg5 on the device against the oracle: one exposure sub-sample of the full scene - all 1 M Gaussians,
+    K = 12 motion bases, the fused deform + project + composite path, raw leaves in - rendered into a 256x256 window of
+    the 1280x720 frame (the camera's principal point shifted by the window origin), against torch-fp64 deformation
+    (oracle/deform.py, F1-pinned) + the scalar-C fp64 rasterizer on the Gaussians that can reach that window (culled on
+    the host by the oracle's own projection; the device gets no such help).  Image and EVERY leaf gradient: per-Gaussian leaves
+    incl. the motion coefficients, and the shared bases."""
+    import ctypes
+
+    import numpy as np
+
+    from deblur4dgs_amd.exposure import render_exposure
+    from oracle import cref, deform
+    from tests.util import check
+
+    dev = scene["means"].device
+    S, W, H = scene["S"], scene["W"], scene["H"]
+    WW = HH = 256
+    x0, y0 = (W - WW) // 2, (H - HH) // 2
+    s = S // 2
+    case = "cfg5 256x256 window, 1 sub-sample, fused path vs torch-fp64 deform + scalar-C fp64"
+    c = {k: (v.cpu().double() if torch.is_tensor(v) else v) for k, v in scene.items()}
+    Kw = c["K"].clone()
+    Kw[0, 2] -= x0
+    Kw[1, 2] -= y0
+    leaf = ("means", "quats", "scales", "opacities", "colors", "motion_coefs")
+    with torch.no_grad():  # host-side cull with the oracle's own projection: which Gaussians can touch the window at all?
+        m, q = deform.compute_poses_fg(c["times"][s:s + 1], c["means"], c["quats"], c["motion_coefs"], c["rots"], c["transls"])
+        m_all = np.ascontiguousarray(deform.camera_delta(m[:, 0], c["RTs"][s]).numpy())
+        q_all = np.ascontiguousarray(q[:, 0].numpy())
+        s_all = np.ascontiguousarray(torch.exp(c["scales"]).numpy())
+        Nall = m_all.shape[0]
+        radii, m2d = np.zeros(Nall, np.int32), np.zeros((Nall, 2))
+        dep, con = np.zeros(Nall), np.zeros((Nall, 3))
+        Lc, P_ = cref.lib(np.float64), cref._p
+        Lc.ref_project_fwd(Nall, P_(m_all), P_(q_all), P_(s_all), P_(np.ascontiguousarray(c["viewmat"].numpy())),
+                           P_(np.ascontiguousarray(Kw.numpy())), WW, HH, ctypes.c_double(0.01), ctypes.c_double(1e10),
+                           ctypes.c_double(0.3), ctypes.c_double(0.0), P_(radii), P_(m2d), P_(dep), P_(con))
+        keep = torch.from_numpy(radii > 0)  # (the projection culls everything whose 3-sigma box misses the window)
+    idx = keep.nonzero()[:, 0]
+    assert 20_000 < idx.numel() < 400_000, idx.numel()
+    o = {k: c[k][idx].clone().requires_grad_() for k in leaf}
+    ob = {k: c[k].clone().requires_grad_() for k in ("rots", "transls")}
+    m, q = deform.compute_poses_fg(c["times"][s:s + 1], o["means"], o["quats"], o["motion_coefs"], ob["rots"], ob["transls"])
+    m = deform.camera_delta(m[:, 0], c["RTs"][s])
+    q = q[:, 0]
+    sc_, op, col = torch.exp(o["scales"]), torch.sigmoid(o["opacities"]), torch.sigmoid(o["colors"])
+    bg = np.array([0.9, 0.5, 0.1])
+    out, al, ctx = cref.rasterization(m.detach().numpy(), q.detach().numpy(), sc_.detach().numpy(), op.detach().numpy(),
+                                      col.detach().numpy(), c["viewmat"].numpy(), Kw.numpy(), WW, HH, background=bg,
+                                      render_mode="RGB+ED", dtype=np.float64)
+    g = torch.Generator().manual_seed(5)
+    wc = torch.randn(HH, WW, 4, generator=g, dtype=torch.float64)
+    ref = cref.backward(ctx, wc.numpy(), np.zeros((HH, WW, 1)))
+    torch.autograd.backward([m, q, sc_, op, col], [torch.from_numpy(ref[k]) for k in ("means", "quats", "scales", "opac", "colors")])
+
+    P = {k: scene[k].detach().clone().requires_grad_() for k in leaf + ("rots", "transls")}
+    res = render_exposure(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], 3, P["motion_coefs"], P["rots"],
+                          P["transls"], scene["times"][s:s + 1], scene["RTs"][s:s + 1], scene["viewmat"], Kw.float().to(dev),
+                          WW, HH, background=torch.tensor(bg, device=dev).float(), return_depth=True, blend=False)
+    (res["renders"][0] * wc.float().to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert 0 < res["state"].n_isect <= ctx["n_isect"]
+    check(case, "render_colors", res["renders"][0].cpu(), out, 1e-4, 1e-4)
+    check(case, "render_alphas", res["alphas"][0].cpu(), al, 1e-4, 1e-4)
+    outside = torch.ones(scene["N"], dtype=torch.bool)
+    outside[idx] = False
+    for name in leaf:
+        gpu = P[name].grad.cpu()
+        check(case, f"grad {name} (window subset)", gpu[idx], o[name].grad, 1e-4, 1e-4)
+        assert float(gpu[outside].abs().max()) == 0.0, name  # nothing outside the host cull reaches the window
+    for name in ("rots", "transls"):  # sums over ~150 k Gaussians: no flip allowance
+        check(case, f"grad bases.{name}", P[name].grad.cpu(), ob[name].grad, 1e-4, 0.0)

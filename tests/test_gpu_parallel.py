@@ -29,8 +29,8 @@ def group():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["views", "exposure"])
-def test_sharded_step_equals_plain_step(group, mode):
+@pytest.mark.parametrize("mode,need_stack", [("views", False), ("exposure", False), ("exposure", True)])
+def test_sharded_step_equals_plain_step(group, mode, need_stack):
     from deblur4dgs_amd.exposure import render_exposure
     from deblur4dgs_amd.parallel import ShardedExposure
 
@@ -52,7 +52,7 @@ def test_sharded_step_equals_plain_step(group, mode):
     (torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))).backward()
 
     got = leaves()
-    sh = ShardedExposure(1, 0, mode=mode)
+    sh = ShardedExposure(1, 0, mode=mode, need_stack=need_stack)  # exposure: reduce-based blend / gathered stack
     for _ in range(2):  # second step: the previous gradients alias the flat buffer and must not be accumulated into
         sh.step(got, K, W, H, bg, wimg, wacc)
     torch.cuda.synchronize()
@@ -63,9 +63,9 @@ def test_sharded_step_equals_plain_step(group, mode):
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()))
 
 
-@pytest.mark.parametrize("mode", ["exposure", "views"])
-def test_sharded_step_with_its_collectives_replays_from_a_hip_graph(group, mode):
-    """The whole sharded step - render, RCCL all-gathers, blend, backward, gradient all-reduce - captured once in a HIP
+@pytest.mark.parametrize("mode,need_stack", [("exposure", False), ("exposure", True), ("views", False)])
+def test_sharded_step_with_its_collectives_replays_from_a_hip_graph(group, mode, need_stack):
+    """The whole sharded step - render, RCCL all-reduces / all-gathers, blend, backward, gradient all-reduce - captured once in a HIP
     graph (deferred size check: no host wait inside) and replayed: bitwise the eager step's gradients, also after the
     parameters have changed in place between replays."""
     from deblur4dgs_amd import engine
@@ -79,7 +79,7 @@ def test_sharded_step_with_its_collectives_replays_from_a_hip_graph(group, mode)
     wimg, wacc = torch.randn(H, W, 4, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
     bg = torch.ones(3, device=dev)
     lv = {k: sc[k].to(dev).clone().requires_grad_() for k in NAMES}
-    sh = ShardedExposure(1, 0, mode=mode)
+    sh = ShardedExposure(1, 0, mode=mode, need_stack=need_stack)
     sh.deferred_size_check = True
 
     def eager():
@@ -116,7 +116,7 @@ def test_sharded_step_with_its_collectives_replays_from_a_hip_graph(group, mode)
 
 
 # ---- world size 2 over RCCL: runs only where two GPUs are visible (the 1-GPU test boxes skip it) -----------------
-def _ws2_worker(rank, port, mode, S, out_q):
+def _ws2_worker(rank, port, mode, S, need_stack, out_q):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
@@ -131,7 +131,7 @@ def _ws2_worker(rank, port, mode, S, out_q):
     g = torch.Generator().manual_seed(2)
     wimg, wacc = torch.randn(H, W, 4, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
     leaves = {k: sc[k].to(dev).clone().requires_grad_() for k in NAMES}
-    sh = ShardedExposure(2, rank, mode=mode)
+    sh = ShardedExposure(2, rank, mode=mode, need_stack=need_stack)
     for _ in range(2):
         sh.step(leaves, sc["K"].to(dev), W, H, torch.ones(3, device=dev), wimg, wacc)
     torch.cuda.synchronize()
@@ -141,11 +141,11 @@ def _ws2_worker(rank, port, mode, S, out_q):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); 1-GPU boxes skip")
-@pytest.mark.parametrize("mode,S", [("exposure", 4), ("exposure", 3), ("views", 4)])
-def test_world_size_2_rccl_step_equals_the_single_process_step(mode, S):
-    """The whole ShardedExposure.step on two ranks: exposure sharding (gather blend for S = 4, the reduce-based blend
-    for the ragged S = 3) must give every rank the single-process gradients of the same frame; view sharding the mean
-    of the two views' gradients."""
+@pytest.mark.parametrize("mode,S,need_stack", [("exposure", 4, False), ("exposure", 4, True), ("exposure", 3, False), ("views", 4, False)])
+def test_world_size_2_rccl_step_equals_the_single_process_step(mode, S, need_stack):
+    """The whole ShardedExposure.step on two ranks: exposure sharding (the reduce-based blend, the gathered stack for
+    need_stack, the ragged S = 3) must give every rank the single-process gradients of the same frame; view sharding the
+    mean of the two views' gradients."""
     import torch.multiprocessing as mp
 
     from deblur4dgs_amd.exposure import render_exposure
@@ -156,7 +156,7 @@ def test_world_size_2_rccl_step_equals_the_single_process_step(mode, S):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ws2_worker, args=(r, port, mode, S, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ws2_worker, args=(r, port, mode, S, need_stack, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(2))
@@ -181,3 +181,73 @@ def test_world_size_2_rccl_step_equals_the_single_process_step(mode, S):
         for k in NAMES:
             tol = 1e-5 * max(1.0, float(want[k].abs().max()))
             assert float((torch.from_numpy(res[rank][k]) - want[k]).abs().max()) <= tol, (mode, rank, k)
+
+
+@pytest.mark.parametrize("S,world,C", [(8, 8, 5), (8, 2, 17), (7, 3, 4), (1, 1, 5)])
+def test_shard_blend_kernels_of_every_rank_combine_to_the_single_gpu_blend(S, world, C):
+    """The HIP kernels of the reduce-based sharded blend (d4gs_blend_shard_*), all `world` ranks emulated on one GPU with the
+    collectives done by hand (SUM of the parts, MAX of the candidates, MIN of the winners): the result must be the
+    single-GPU blend (exposure.BlendFn) - max / min channels and every gradient exactly, mean channels up to fp32
+    summation order (2e-6 * max|value|) - including the reference's max{raw_0..S-2, mean} quirk and exact ties."""
+    import ctypes as Ct
+
+    from deblur4dgs_amd import _lib as L
+    from deblur4dgs_amd.engine import _stream
+    from deblur4dgs_amd.exposure import BlendFn, reference_policy
+    from deblur4dgs_amd.parallel import _shard_desc, owned_subsamples
+
+    dev = torch.device("cuda", 0)
+    H, W = 37, 21
+    g = torch.Generator().manual_seed(5)
+    renders = torch.rand(S, H, W, C, generator=g)
+    renders[:, 0, 0, 3] = 0.0          # exact ties on the max channel
+    renders[S - 1, 1, 1, 3] = 5.0      # the last sub-sample would win: the reference's max runs over {raw_0..S-2, mean}
+    alphas = torch.rand(S, H, W, generator=g)
+    v_out, v_acc = torch.randn(H, W, C, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
+    renders, alphas = renders.to(dev), alphas.to(dev)
+    pol = reference_policy(C)
+    npol = sum(1 for p in pol if p)
+    r_ref = renders.clone().requires_grad_()
+    a_ref = alphas.clone().requires_grad_()
+    out_ref, acc_ref = BlendFn.apply(r_ref, a_ref, pol)
+    torch.autograd.backward([out_ref, acc_ref], [v_out, v_acc])
+
+    lib = L.lib()
+    parts, cands, descs, locs = [], [], [], []
+    for r in range(world):
+        own = owned_subsamples(S, world, r)
+        lr, la = renders[own].contiguous(), alphas[own].contiguous()
+        desc, keep = _shard_desc(len(own), S, own, C, H * W, pol)
+        part = torch.empty(H, W, C + 1, device=dev)
+        cand = torch.empty(H, W, max(npol, 1), device=dev)
+        L.check(lib.d4gs_blend_shard_partial_fwd(Ct.byref(desc), L.ptr(lr), L.ptr(la), L.ptr(part), L.ptr(cand), _stream()), "partial")
+        parts.append(part), cands.append(cand), descs.append((desc, keep)), locs.append((own, lr, la))
+    part = torch.stack(parts).sum(0)              # all-reduce SUM
+    cand = torch.stack(cands).amax(0)             # all-reduce MAX
+    out, acc = torch.empty(H, W, C, device=dev), torch.empty(H, W, device=dev)
+    L.check(lib.d4gs_blend_shard_finish_fwd(Ct.byref(descs[0][0]), L.ptr(part), L.ptr(cand), L.ptr(out), L.ptr(acc), _stream()), "finish")
+    tol = 2e-6 * float(out_ref.abs().max())
+    assert float((out - out_ref).abs().max()) <= tol and float((acc - acc_ref).abs().max()) <= 2e-6
+    pc = [c for c, p in enumerate(pol) if p]
+    if S > 1 and pc:  # the policy channels are a max / min over exact values or the mean
+        d = (out[..., pc] - out_ref[..., pc]).abs()
+        assert float(d.max()) <= tol
+    wins = []
+    for r in range(world):
+        own, lr, la = locs[r]
+        win = torch.empty(H, W, max(npol, 1), dtype=torch.int32, device=dev)
+        # (each rank compares with the REDUCED image, as after the forward collectives)
+        L.check(lib.d4gs_blend_shard_winner(Ct.byref(descs[r][0]), L.ptr(lr), L.ptr(out), L.ptr(win), _stream()), "winner")
+        wins.append(win)
+    win = torch.stack(wins).amin(0) if npol and S > 1 else wins[0]  # all-reduce MIN
+    for r in range(world):
+        own, lr, la = locs[r]
+        v_r, v_a = torch.empty_like(lr), torch.empty_like(la)
+        L.check(lib.d4gs_blend_shard_bwd(Ct.byref(descs[r][0]), L.ptr(v_out), L.ptr(v_acc), L.ptr(win), L.ptr(v_r), L.ptr(v_a),
+                                         _stream()), "bwd")
+        torch.cuda.synchronize()
+        if len(own):
+            # where the sharded mean differs from the stacked mean by an ulp, a max / min that equals the MEAN may pick a
+            # different winner only if a raw value ties with it to the last bit - not in this data: exact equality
+            assert torch.equal(v_r, r_ref.grad[own]), r
+            assert torch.equal(v_a, a_ref.grad[own]), r

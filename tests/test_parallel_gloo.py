@@ -30,7 +30,7 @@ def _tensors(items):
     return tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in items)
 
 
-def _worker(rank, world, port, S, C, seed, q):
+def _worker(rank, world, port, S, C, seed, q, dtype=torch.float64):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from deblur4dgs_amd.exposure import reference_policy
@@ -38,13 +38,13 @@ def _worker(rank, world, port, S, C, seed, q):
 
     g = torch.Generator().manual_seed(seed)
     H, W = 6, 5
-    renders = torch.rand(S, H, W, C, generator=g, dtype=torch.float64)
+    renders = torch.rand(S, H, W, C, generator=g, dtype=dtype)
     renders[:, 0, 0, 3] = 0.0  # exact ties on the max-policy channel (e.g. mask == 0 everywhere)
     renders[S - 1, 1, 1, 3] = 5.0  # the LAST sub-sample holds the max: the reference takes max{raw_0..S-2, mean}
-    alphas = torch.rand(S, H, W, generator=g, dtype=torch.float64)
-    wb = torch.randn(H, W, C, generator=g, dtype=torch.float64)
-    wa = torch.randn(H, W, generator=g, dtype=torch.float64)
-    scale = torch.ones(S, dtype=torch.float64, requires_grad=True)  # a "leaf" every sub-sample depends on
+    alphas = torch.rand(S, H, W, generator=g, dtype=dtype)
+    wb = torch.randn(H, W, C, generator=g, dtype=dtype)
+    wa = torch.randn(H, W, generator=g, dtype=dtype)
+    scale = torch.ones(S, dtype=dtype, requires_grad=True)  # a "leaf" every sub-sample depends on
     own = owned_subsamples(S, world, rank)
     loc = (renders[own] * scale[own].view(-1, 1, 1, 1)).requires_grad_() if False else renders[own] * scale[own].view(-1, 1, 1, 1)
     loc.retain_grad()
@@ -95,6 +95,45 @@ def test_sharded_blend_matches_reference_blend(world, S, C):
         torch.testing.assert_close(gr, r.grad[own], rtol=0, atol=1e-12)
         torch.testing.assert_close(ga, a.grad[own], rtol=0, atol=1e-12)
         torch.testing.assert_close(gscale, scale.grad, rtol=0, atol=1e-11)  # all-reduced leaf gradient
+
+
+@pytest.mark.parametrize("world,S,C", [(2, 8, 5), (3, 6, 17)])
+def test_reduce_blend_in_fp32_equals_the_single_process_blend_within_summation_order(world, S, C):
+    """The DEFAULT forward collective of exposure sharding: SUM all-reduce of [H,W,D'+1] + MAX all-reduce of the
+    policy channels, in the path's own precision (fp32).  It adds the sub-samples in a different order than the stacked
+    single-process blend (rank-local partial sums first), so equality is up to fp32 summation order: the stated
+    tolerance is 2e-6 * max|value| (S <= 16 terms of magnitude <= max: a few ulps) for the image, the accumulation and
+    every local gradient; the gathered-stack path below keeps the bitwise claim."""
+    from oracle import scene as oscene
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, S, C, 17, q, torch.float32)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [_tensors(q.get(timeout=120)) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(17)
+    H, W = 6, 5
+    renders = torch.rand(S, H, W, C, generator=g, dtype=torch.float32)
+    renders[:, 0, 0, 3] = 0.0
+    renders[S - 1, 1, 1, 3] = 5.0
+    alphas = torch.rand(S, H, W, generator=g, dtype=torch.float32)
+    wb = torch.randn(H, W, C, generator=g, dtype=torch.float32)
+    wa = torch.randn(H, W, generator=g, dtype=torch.float32)
+    r = renders.double().requires_grad_()
+    a = alphas.double().requires_grad_()
+    blended, acc, _ = oscene.blend_exposure([r[s][None] for s in range(S)], [a[s][None] for s in range(S)], single=(S == 1))
+    ((blended[0] * wb.double()).sum() + (acc[0] * wa.double()).sum()).backward()
+    TOL = 2e-6
+    for rank, own, out, acc_r, gr, ga, _gscale in res:
+        assert out.dtype == torch.float32
+        for got, want in ((out, blended[0]), (acc_r, acc[0]), (gr, r.grad[own]), (ga, a.grad[own])):
+            want = want.detach()
+            assert float((got.double() - want).abs().max()) <= TOL * max(1.0, float(want.abs().max()))
 
 
 def _oracle_blend(renders, alphas, policy):
