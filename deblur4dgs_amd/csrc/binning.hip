@@ -203,32 +203,83 @@ __device__ __forceinline__ void chunk_block(uint64_t (&v)[NV], int lane) {  // t
   chunk_plain<K / 4, NV>(v, lane);
 }
 
-// LDS form.  `key[0..P)` holds the list padded with UINT64_MAX to a power of two P >= 64.  All steps whose partner
-// distance is < 64 run inside one wave on 64-key chunks held in registers - four chunks per wave at a time, so the
-// exchange latencies overlap - and the k-blocks 2..64 run back to back without touching LDS; only the steps with
-// distance >= 64 go through LDS with a barrier each.
+// ---- 512-key chunks in registers (round 3) ---------------------------------------------------------------------------
+// A wave holds a chunk of 64 * NV keys as NV registers per lane (key index u * 64 + lane).  Inside the chunk every step
+// of the network stays in registers: partner distances < 64 are the DPP / bpermute lane exchanges above, distances
+// 64 .. 32 NV pair two REGISTERS of the same lane (a plain compare-exchange, no cross-lane traffic at all), and a
+// k-block's flip step pairs register u of lane l with the mirrored register of lane 63 - l.  A list of up to 512 keys
+// is therefore sorted by ONE wave without LDS or barriers (round 2: 6 LDS passes + barriers for 512 keys), and longer
+// lists only go through LDS for distances >= 512 (4096 keys: 6 LDS passes instead of 21).
+__device__ __forceinline__ uint64_t rev64(uint64_t v) { return shfl_xor_u64(v, 63); }
+__device__ __forceinline__ void reg_cex(uint64_t &lo, uint64_t &hi) {  // lo = min, hi = max
+  const uint64_t a = lo, b = hi;
+  const bool sw = a > b;
+  lo = sw ? b : a, hi = sw ? a : b;
+}
+template <int NV, int D>
+__device__ __forceinline__ void reg_flip(uint64_t (&v)[NV]) {  // flip step of the k-block k = 64 D
+#pragma unroll
+  for (int base = 0; base < NV; base += D)
+#pragma unroll
+    for (int h = 0; h < D / 2; h++) {
+      const int a = base + h, b = base + D - 1 - h;
+      const uint64_t ra = rev64(v[a]), rb = rev64(v[b]);
+      v[a] = v[a] < rb ? v[a] : rb;  // lower index keeps the smaller key
+      v[b] = v[b] > ra ? v[b] : ra;
+    }
+}
+template <int NV, int R>
+__device__ __forceinline__ void reg_plain(uint64_t (&v)[NV]) {  // plain steps at register distances R, R/2, .., 1
+  if constexpr (R >= 1) {
+#pragma unroll
+    for (int u = 0; u < NV; u++)
+      if ((u / R) % 2 == 0) reg_cex(v[u], v[u + R]);
+    reg_plain<NV, R / 2>(v);
+  }
+}
+template <int NV>
+__device__ __forceinline__ void chunk_sort(uint64_t (&v)[NV], int lane) {  // the whole network on 64 NV keys
+  chunk_block<2, NV>(v, lane);
+  chunk_block<4, NV>(v, lane);
+  chunk_block<8, NV>(v, lane);
+  chunk_block<16, NV>(v, lane);
+  chunk_block<32, NV>(v, lane);
+  chunk_block<64, NV>(v, lane);
+  if constexpr (NV >= 2) {
+    reg_flip<NV, 2>(v);
+    chunk_plain<32, NV>(v, lane);
+  }
+  if constexpr (NV >= 4) {
+    reg_flip<NV, 4>(v);
+    reg_plain<NV, 1>(v);
+    chunk_plain<32, NV>(v, lane);
+  }
+  if constexpr (NV >= 8) {
+    reg_flip<NV, 8>(v);
+    reg_plain<NV, 2>(v);
+    chunk_plain<32, NV>(v, lane);
+  }
+}
+constexpr int CNV = 8, CHUNK = 64 * CNV;  // keys per lane / per chunk
+
+// LDS form.  `key[0..P)` holds the list padded with UINT64_MAX to a power of two P >= CHUNK.  Chunks of 512 keys are
+// sorted in registers; only the steps with distance >= 512 go through LDS with a barrier each.
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t *key, int P, int n) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // keys [n, P) are UINT64_MAX padding: in this all-ascending network a pair whose upper partner is padding never
   // swaps, so chunks made of padding only and cross-chunk pairs reaching into it are skipped (work ~ n, not P)
-  const int nchunks = (n + 63) >> 6;
-  for (int c0 = wv; c0 < nchunks; c0 += 4 * nw) {
-    uint64_t v[4];
+  const int nchunks = (n + CHUNK - 1) / CHUNK;
+  for (int c = wv; c < nchunks; c += nw) {
+    uint64_t v[CNV];
 #pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = (c0 + u * nw < nchunks) ? key[(c0 + u * nw) * 64 + lane] : ~0ull;
-    chunk_block<2, 4>(v, lane);
-    chunk_block<4, 4>(v, lane);
-    chunk_block<8, 4>(v, lane);
-    chunk_block<16, 4>(v, lane);
-    chunk_block<32, 4>(v, lane);
-    chunk_block<64, 4>(v, lane);
+    for (int u = 0; u < CNV; u++) v[u] = key[c * CHUNK + u * 64 + lane];
+    chunk_sort<CNV>(v, lane);
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (c0 + u * nw < nchunks) key[(c0 + u * nw) * 64 + lane] = v[u];
+    for (int u = 0; u < CNV; u++) key[c * CHUNK + u * 64 + lane] = v[u];
   }
   __syncthreads();
-  for (int k = 128; k <= P; k <<= 1) {
-    for (int j = k >> 1; j >= 64; j >>= 1) {  // cross-chunk steps
+  for (int k = 2 * CHUNK; k <= P; k <<= 1) {
+    for (int j = k >> 1; j >= CHUNK; j >>= 1) {  // cross-chunk steps
       for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
         const int blk = t / j, off = t - blk * j;
         const int i = blk * 2 * j + off;
@@ -240,14 +291,14 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t *key, int P, int n) {
       }
       __syncthreads();
     }
-    for (int c0 = wv; c0 < nchunks; c0 += 4 * nw) {  // distances 32 .. 1
-      uint64_t v[4];
+    for (int c = wv; c < nchunks; c += nw) {  // distances 256 .. 1
+      uint64_t v[CNV];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = (c0 + u * nw < nchunks) ? key[(c0 + u * nw) * 64 + lane] : ~0ull;
-      chunk_plain<32, 4>(v, lane);
+      for (int u = 0; u < CNV; u++) v[u] = key[c * CHUNK + u * 64 + lane];
+      reg_plain<CNV, CNV / 2>(v);
+      chunk_plain<32, CNV>(v, lane);
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (c0 + u * nw < nchunks) key[(c0 + u * nw) * 64 + lane] = v[u];
+      for (int u = 0; u < CNV; u++) key[c * CHUNK + u * 64 + lane] = v[u];
     }
     __syncthreads();
   }
@@ -262,7 +313,40 @@ struct SortArgs {
   int lo, cap;  // this launch sorts the lists with lo < n <= cap in LDS; cap < 0: everything longer, in global memory
   const int64_t *n_dev;
   int64_t n_cap, max_hint;
+  int n_lists;
 };
+
+// lists of up to 512 keys: one WAVE per list, straight from global memory into registers and back - no LDS, no barrier
+template <int NV>
+__device__ __forceinline__ void wave_sort_list(const SortArgs &a, int base, int n, int lane) {
+  uint64_t v[NV];
+  const uint64_t *gk = a.keys + base;
+#pragma unroll
+  for (int u = 0; u < NV; u++) v[u] = (u * 64 + lane < n) ? gk[u * 64 + lane] : ~0ull;
+  chunk_sort<NV>(v, lane);
+#pragma unroll
+  for (int u = 0; u < NV; u++) {
+    const int p = u * 64 + lane;
+    if (p < n) {
+      const uint32_t e = (uint32_t)v[u];
+      a.sorted_emit[base + p] = (int32_t)e;
+      a.sorted_gid[base + p] = a.gid_of_emit[e];
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_tile_sort_w(const SortArgs a) {
+  if (over_capacity(a.n_dev, a.n_cap, a.max_hint)) return;
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= a.n_lists) return;
+  const int base = a.tile_offsets[t];
+  const int n = a.tile_offsets[t + 1] - base;
+  if (n <= 0 || n > CHUNK) return;
+  if (n <= 64) wave_sort_list<1>(a, base, n, lane);
+  else if (n <= 128) wave_sort_list<2>(a, base, n, lane);
+  else if (n <= 256) wave_sort_list<4>(a, base, n, lane);
+  else wave_sort_list<8>(a, base, n, lane);
+}
 
 __global__ void __launch_bounds__(1024) k_tile_sort(const SortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
@@ -273,7 +357,7 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const SortArgs a) {
   if (n <= a.lo || (a.cap >= 0 && n > a.cap)) return;
   uint64_t *gk = a.keys + base;
   if (a.cap >= 0) {
-    int P = 64;
+    int P = CHUNK;
     while (P < n) P <<= 1;
     for (int p = threadIdx.x; p < P; p += blockDim.x) skeys[p] = p < n ? gk[p] : ~0ull;
     __syncthreads();
@@ -327,19 +411,25 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   int rc = d4gs_check_launch("k_emit");
   if (rc) return rc;
   const int n_tiles = dims->S * e.tw * e.th;
-  // Size classes, one launch each (a workgroup exits at once if its list is not in the class): the LDS a workgroup
-  // reserves and its width follow the list length - 16 KB / 256 lanes up to 2048 keys (8+ workgroups per CU) ...
+  // Size classes, one launch each (a workgroup exits at once if its list is not in the class): lists of up to 512 keys take
+  // one wave each, in registers (k_tile_sort_w); beyond that the LDS a workgroup reserves and its width follow the list
+  // length - 16 KB / 256 lanes up to 2048 keys (8+ workgroups per CU) ...
   // 128 KB / 1024 lanes up to 16384 keys, anything longer in global memory.  (Round 1 had only the 16 KB and 128 KB
   // classes: a scene whose lists run to ~4 k keys sorted them one workgroup of 4 waves per CU - 1.54 ms on cfg2 with
   // 4x larger splats.)
   // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
   (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-  const int classes[6][3] = {{0, 2048, 256}, {2048, 4096, 512}, {4096, 8192, 1024}, {8192, 16384, 1024}, {16384, -1, 1024}};
+  {  // lists of up to 512 keys: one wave each, in registers
+    SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
+               0, CHUNK, proj->n_isect, isect->n_isect, isect->max_tile_count, n_tiles};
+    D4GS_LAUNCH("k_tile_sort_w", k_tile_sort_w, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, s);
+  }
+  const int classes[6][3] = {{CHUNK, 2048, 256}, {2048, 4096, 512}, {4096, 8192, 1024}, {8192, 16384, 1024}, {16384, -1, 1024}};
   for (int c = 0; c < 5; c++) {
     const int64_t longest = isect->max_tile_count > 0 ? isect->max_tile_count : isect->n_isect;
-    if (c > 0 && longest <= classes[c][0]) break;  // no list is that long
+    if (longest <= classes[c][0]) break;  // no list is that long
     SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
-               classes[c][0], classes[c][1], proj->n_isect, isect->n_isect, isect->max_tile_count};
+               classes[c][0], classes[c][1], proj->n_isect, isect->n_isect, isect->max_tile_count, n_tiles};
     const size_t lds = classes[c][1] > 0 ? (size_t)classes[c][1] * 8 : 0;
     D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(classes[c][2]), lds, stream, s);
   }

@@ -133,7 +133,7 @@ _PINNED: dict = {}
 def _sort_class(max_tile: int) -> int:
     """Upper bound on the longest tile list handed to d4gs_bin_sort (with 50 % headroom), rounded to a sort size class;
     0 = unknown (every class is launched)."""
-    for c in (2048, 4096, 8192, 16384):
+    for c in (512, 2048, 4096, 8192, 16384):
         if 3 * max_tile <= 2 * c:
             return c
     return 0
@@ -527,6 +527,7 @@ class FrameFn(torch.autograd.Function):
         st.binned = True
         st.frame_io, st.policy = io, pol
         ctx.st = st
+        ctx.set_materialize_grads(False)  # an output the loss does not use must arrive as None, not as a zero-filled stack
         ctx.save_for_backward(*[st.proj_in[k] for k in _PROJ_IN])  # version-checked, like ProjectFn
         ctx.needs = [t is not None and t.requires_grad for t in
                      (means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs, viewmat)]
@@ -632,6 +633,7 @@ class PosesFn(torch.autograd.Function):
             L.check(L.lib().d4gs_poses_fwd(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pin)), C.byref(po), _stream()),
                     "d4gs_poses_fwd")
         ctx.cfg, ctx.g_major, ctx.want = cfg, bool(g_major), want
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None (no zero-filled [N,B,...] gradients to stream)
         ctx.keys = [k for k, v in pin.items() if v is not None]
         ctx.save_for_backward(*[pin[k] for k in ctx.keys])  # version-checked, like ProjectFn
         ctx.needs = [t is not None and t.requires_grad for t in (means, quats, motion_coefs, rots, transls, ts, w2cs34)]
