@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on its config: "Gaussians/s fwd+bwd, 288x512, N_exposure=8".
 
-A step = ONE blurry frame, forward + backward: raw leaf params -> activations -> motion-basis deformation of all
+A step = ONE blurry frame, forward + backward, through the one-call entry points d4gs_forward / d4gs_backward behind
+one autograd node (`--staged`: the five staged entry points behind three nodes; same kernels): raw leaf params -> activations -> motion-basis deformation of all
 S exposure sub-samples -> camera delta -> projection -> tile binning + per-tile depth sort -> composite ->
 exposure blend -> loss = <blended, Wimg> + <acc, Wacc> -> gradients to every leaf (means, quats, scales,
 opacities, colours, motion coefficients, bases, times, camera deltas, viewmat).  Inputs are resident in HBM
@@ -13,9 +14,11 @@ run_training_dynamic.py:118-120, scene_model.py:233-296).  `--scale-mul F` multi
 (SURVEY 8d's distribution has sub-2-pixel splats; real scenes have larger footprints).
 
 N GPUs (torchrun, one rank per GPU, RCCL): the default is BASELINE config 4 - `--shard exposure`: the S sub-samples of
-the SAME frame are split over the ranks, the blended image is an all-reduce (SUM, + MAX/MIN channels), leaf gradients
-are all-reduced; total work is fixed -> "scaling": "strong", value = N / t, and the N = 1 value equals the single-GPU
-line.  The view-sharded (data-parallel) throughput - every rank renders its own full frame, "weak" scaling,
+the SAME frame are split over the ranks, the blended frame is REDUCED (SUM all-reduce of colours + alpha, MAX all-reduce of
+the max / min policy channels; HIP kernels d4gs_blend_shard_* around the collectives), the backward needs one MIN
+all-reduce of the winning sub-sample, leaf gradients are all-reduced; the whole step, collectives included, is replayed
+from ONE HIP graph (`--no-graph`: eager).  Total work is fixed -> "scaling": "strong", value = N / t, and the N = 1
+value equals the single-GPU line.  The view-sharded (data-parallel) throughput - every rank renders its own full frame, "weak" scaling,
 value = world * N / t - is measured right after the timed region and reported as the secondary object
 `views_weak_scaling`.  `--shard views` makes it the primary line instead.
 """
@@ -257,11 +260,35 @@ def _load_json(*rel):
         return None
 
 
+_LIB_SHA = None
+
+
+def _lib_sha():
+    """sha256 of the libd4gs.so this run loads: the committed counter files (profiles/pmc_traffic.json,
+    profiles/<round>_pmc_sq_cfg2.json) carry the hash of the build they were measured on and are only quoted while it
+    matches - a stale profile must not dress up a changed kernel."""
+    global _LIB_SHA
+    if _LIB_SHA is None:
+        import hashlib
+
+        from deblur4dgs_amd import _lib as L
+
+        _LIB_SHA = hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()
+    return _LIB_SHA
+
+
+def _counters_current(doc):
+    return bool(doc) and doc.get("lib_sha256") == _lib_sha()
+
+
 def _traffic(name, kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs, KB
     units; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-counts wide coalesced reads up to 2x, so the read term is
     reported both ways)."""
-    pm = (_load_json("profiles", "pmc_traffic.json") or {}).get(name, {}).get("kernels", {}).get(kernel)
+    doc = _load_json("profiles", "pmc_traffic.json")
+    if not _counters_current(doc):
+        return None  # measured on another build of the kernels
+    pm = doc.get(name, {}).get("kernels", {}).get(kernel)
     if not pm:
         return None
     f, w = pm["FETCH_SIZE"] * 1024.0, pm["WRITE_SIZE"] * 1024.0
@@ -512,12 +539,21 @@ def main():
                                 "pair the kernel replays, although the kernel skips most of those pixels by design; the "
                                 "`hardware` object below says what the VALU actually does"}
                 # what the hardware does, from the committed PMC pass + the offline lane statistics of the same scene
-                sq = (_load_json("profiles", "r02_pmc_sq_cfg2.json") or {}).get(dom) if name == "cfg2" and channels == 3 else None
-                lanes = _load_json("profiles", "r02_lane_stats_cfg2.json") if name == "cfg2" and channels == 3 else None
+                cur = _load_json("profiles", "pmc_current.json") or {}
+                sq_doc = _load_json("profiles", f"{cur.get('round', 'r03')}_pmc_sq_cfg2.json")
+                sq_ok = _counters_current(sq_doc) and name == "cfg2" and channels == 3 and args.scale_mul == 1.0
+                sq = sq_doc.get(dom) if sq_ok else None
+                lanes = _load_json("profiles", "r02_lane_stats_cfg2.json") if sq_ok else None  # (a property of the scene and
+                #                                       of the quadrant mapping, both unchanged since round 2)
+                if not sq_ok and name == "cfg2" and channels == 3:
+                    roof["counters_note"] = ("profiles/ holds PMC counters of another build of libd4gs.so (sha256 mismatch): "
+                                             "`traffic` / `hardware` omitted rather than quoted stale; scripts/profile_round.sh "
+                                             "re-measures them")
                 if sq:
                     clk_cycles = sq["GRBM_GUI_ACTIVE"] / N_XCD  # the counter is summed over the 8 XCDs
                     insts = sq["SQ_INSTS_VALU"]
-                    hw = {"source": "profiles/r02_pmc_sq_cfg2.json (rocprofv3 --pmc, own pass), profiles/r02_lane_stats_cfg2.json",
+                    hw = {"source": f"profiles/{cur.get('round', 'r03')}_pmc_sq_cfg2.json (rocprofv3 --pmc, own pass, same libd4gs.so by "
+                                    "sha256), profiles/r02_lane_stats_cfg2.json",
                           "valu_wave_insts_per_launch": insts, "kernel_cycles": clk_cycles,
                           "cycles_per_valu_inst_per_simd": clk_cycles * N_SIMD / insts,
                           "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] / (clk_cycles * N_CU),

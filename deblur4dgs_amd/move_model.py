@@ -89,8 +89,11 @@ class MoveModelFn(torch.autograd.Function):
                                             int(stage_first), C.byref(out), _stream(R)), "move_model_fwd")
         # The parameters go through save_for_backward so that an in-place update between forward and backward
         # (optimizer.step, load_state_dict) raises instead of silently differentiating the wrong weights.
-        ctx.save_for_backward(tp, *ws, *bs)
-        ctx.keep = (buf, R, T)  # buffers this function created itself
+        # ... and so do the detached aliases of the caller's pose: the pose-gradient backward re-reads R / T, and an in-place
+        # pose update between forward and backward (test-time pose refinement, flow3d/validator.py:442-448) must raise
+        # rather than be differentiated at the wrong point
+        ctx.save_for_backward(tp, *ws, *bs, R, T)
+        ctx.keep = (buf,)  # the buffer this function created itself
         ctx.meta = (S, index, time_params.shape, [x.shape for x in wb], t_shape)
         return RTs.view(S, 3, 4), times.view(1, S), dT[:1].view(1, 1)
 
@@ -99,8 +102,8 @@ class MoveModelFn(torch.autograd.Function):
         from . import _lib as L
 
         tp, *wsbs = ctx.saved_tensors
-        ws, bs = wsbs[:9], wsbs[9:]
-        buf, R, T = ctx.keep
+        ws, bs, (R, T) = wsbs[:9], wsbs[9:18], wsbs[18:]
+        (buf,) = ctx.keep
         S, index, tp_shape, shapes, t_shape = ctx.meta
         enc, acts, delta, RTs, jac, times, dtimes, dT = buf.split([P_input_ch, MLP_ACTS, 12, S * 12, S * 144, S, S, 2])
         cont = lambda v: None if v is None else v.contiguous().float()
@@ -209,6 +212,11 @@ class MoveModel(nn.Module):
         _need_gpu(R)
         from . import _lib as L
 
+        if torch.is_grad_enabled() and (R.requires_grad or T.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # (the reference's forward is differentiable; nothing on the render path calls it - silently returning
+            # graph-less tensors would hand a caller zero / None gradients)
+            raise RuntimeError("deblur4dgs_amd MoveModel.forward returns values only (no autograd graph): differentiate through "
+                               "forward_start_end_mid(), or call it under torch.no_grad()")
         lay = [p.detach().contiguous() for p in self._layer_params()]
         tp = self.time_params.detach().contiguous()
         S = 2

@@ -2,7 +2,7 @@
 """gpurun_out/pmc_<tag>_{fetch,write,sq}.txt (scripts/pmc_run.sh via scripts/profile_round.sh) ->
 profiles/pmc_traffic.json (FETCH_SIZE / WRITE_SIZE, KB per launch, per kernel) and profiles/<round>_pmc_sq_<cfg>.json
 (SQ / GRBM counters per launch).   usage: pmc_to_json.py <tag> <round> [cfg]"""
-import json, re, sys
+import hashlib, json, os, re, sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
 cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
@@ -19,6 +19,9 @@ def parse(path):
     return out
 
 
+# the counters describe ONE build of the kernels: bench.py only quotes them while libd4gs.so still hashes to this
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deblur4dgs_amd", "libd4gs.so")
+lib_sha = hashlib.sha256(open(LIB, "rb").read()).hexdigest()
 traffic = {}
 for part in ("fetch", "write"):
     for k, v in parse(f"gpurun_out/pmc_{tag}_{part}.txt").items():
@@ -26,6 +29,10 @@ for part in ("fetch", "write"):
 doc = {cfg: {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only), "
                        f"profiles/{rnd}_pmc_fetch_{cfg}.txt / {rnd}_pmc_write_{cfg}.txt; KB per launch",
              "kernels": {k: v for k, v in traffic.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}}}
+doc["lib_sha256"] = lib_sha
 json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
-json.dump(parse(f"gpurun_out/pmc_{tag}_sq.txt"), open(f"profiles/{rnd}_pmc_sq_{cfg}.json", "w"), indent=1)
+sq = parse(f"gpurun_out/pmc_{tag}_sq.txt")
+sq["lib_sha256"] = lib_sha
+json.dump(sq, open(f"profiles/{rnd}_pmc_sq_{cfg}.json", "w"), indent=1)
+json.dump({"lib_sha256": lib_sha, "round": rnd}, open("profiles/pmc_current.json", "w"), indent=1)
 print("kernels:", sorted(doc[cfg]["kernels"]))

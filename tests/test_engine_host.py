@@ -21,7 +21,8 @@ def test_channel_chunks_cover_every_count_with_instantiated_widths():
 
 
 def test_sort_classes_leave_headroom_and_fall_back_to_unknown():
-    assert engine._sort_class(0) == 2048 and engine._sort_class(1365) == 2048
+    assert engine._sort_class(0) == 512 and engine._sort_class(341) == 512  # one wave, registers only (k_tile_sort_w)
+    assert engine._sort_class(342) == 2048 and engine._sort_class(1365) == 2048
     assert engine._sort_class(1366) == 4096 and engine._sort_class(5000) == 8192 and engine._sort_class(10922) == 16384
     assert engine._sort_class(10923) == 0  # longer than the largest LDS class with 50 % headroom: every class is launched
 
