@@ -68,8 +68,11 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// amdgpu_waves_per_eu(8, 8): the kernel's time follows ~ 415 us + 2000 us / (waves per SIMD) on cfg2 (measured by padding the
+// workgroup's LDS: 2 -> 1413, 3 -> 1034, 4 -> 863, 7 -> 700 us); asked for 8 the compiler fits D <= 5 in 52-64 VGPRs without
+// scratch (68 before: 7 waves): 700 -> 687 us.  The wide instantiations (D = 8, 16) keep their registers - the hint cannot be met.
 template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 5 ? 8 : 1, 8))) k_raster_bwd_q(const RasterBwdArgs a) {
 #pragma clang fp contract(off)
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;

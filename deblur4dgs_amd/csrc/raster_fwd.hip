@@ -50,8 +50,26 @@ __device__ __forceinline__ int xcd_remap(int b, int n_blocks) {
 // order preserved) and the rows walk their own lists in lock-step: iteration i composites up to four different splats.
 // Per-pixel arithmetic and order are unchanged -> bit-identical to variants A and B.
 // ---------------------------------------------------------------------------------------------------------------
+// A staged splat's tight alpha >= 1/255 box, relative to the tile origin, as 4 x f16 (8 bytes instead of 16: the batch
+// arrays fit 20 KB and 8 workgroups share a CU).  Only the range around the tile matters, so the bounds are clamped to
+// [-32, 48] (f16 spacing <= 1/32 there) and widened by 0.04 px before the round-to-nearest conversion: the packed box
+// always contains the exact one.  It is a filter - the per-pixel alpha test decides - so the image does not change.
+__device__ __forceinline__ uint2 pack_box(float x0, float x1, float y0, float y1) {
+  const float lo = -32.f, hi = 48.f;
+  x0 = fminf(fmaxf(x0 - 0.04f, lo), hi), x1 = fminf(fmaxf(x1 + 0.04f, lo), hi);
+  y0 = fminf(fmaxf(y0 - 0.04f, lo), hi), y1 = fminf(fmaxf(y1 + 0.04f, lo), hi);
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 a = {(_Float16)x0, (_Float16)x1}, b = {(_Float16)y0, (_Float16)y1};
+  return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+}
+__device__ __forceinline__ float4 unpack_box(uint2 p) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 a = __builtin_bit_cast(h2, p.x), b = __builtin_bit_cast(h2, p.y);
+  return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+
 template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 4 ? 8 : 1, 8))) k_raster_fwd_r(const RasterFwdArgs a) {
 #pragma clang fp contract(off)
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
@@ -60,7 +78,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
                                            // batches keep 4+ workgroups per CU (measured 17-ch: 0.45 -> 0.42 ms)
   __shared__ float4 sg0[FB];
   __shared__ float4 sg1[FB];
-  __shared__ float4 sbox[FB];
+  __shared__ uint2 sbox[FB];  // tight box in tile-local pixels as 4 x f16 (widened: conservative), see pack_box
   __shared__ float4 scol[FB * DV];
   __shared__ unsigned char slist[4 * 4 * FB];  // [wave][row][position]
 
@@ -78,8 +96,11 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
   const bool inside = x < a.width && y < a.height;
   const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
   // pixel-centre extents of the two block columns / block rows of this quadrant
-  const float xl0 = (float)qx0 + 0.5f, xh0 = (float)qx0 + 3.5f, xl1 = (float)qx0 + 4.5f, xh1 = (float)qx0 + 7.5f;
-  const float yl0 = (float)qy0 + 0.5f, yh0 = (float)qy0 + 3.5f, yl1 = (float)qy0 + 4.5f, yh1 = (float)qy0 + 7.5f;
+  // (tile-local: the staged boxes are relative to the tile origin)
+  const float tx0f = (float)(tx * D4GS_TILE), ty0f = (float)(ty * D4GS_TILE);
+  const float qlx = (float)((wv & 1) * 8), qly = (float)((wv >> 1) * 8);
+  const float xl0 = qlx + 0.5f, xh0 = qlx + 3.5f, xl1 = qlx + 4.5f, xh1 = qlx + 7.5f;
+  const float yl0 = qly + 0.5f, yh0 = qly + 3.5f, yl1 = qly + 4.5f, yh1 = qly + 7.5f;
   unsigned char *wlist = slist + wv * 4 * FB;
   const unsigned char *mylist = wlist + row * FB;
 
@@ -108,7 +129,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
         ex = sqrtf(2.f * tau * q1.z * idet) + 1e-3f;
         ey = sqrtf(2.f * tau * q1.x * idet) + 1e-3f;
       }
-      sbox[tid] = ex < 0.f ? make_float4(1e30f, -1e30f, 1e30f, -1e30f) : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
+      sbox[tid] = ex < 0.f ? pack_box(1e30f, -1e30f, 1e30f, -1e30f) : pack_box(q0.x - ex - tx0f, q0.x + ex - tx0f, q0.y - ey - ty0f, q0.y + ey - ty0f);
       const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
 #pragma unroll
       for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
@@ -122,7 +143,7 @@ __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
       const int jj = k * 64 + lane;
       bool h0 = false, h1 = false, h2 = false, h3 = false;
       if (jj < nb) {
-        const float4 bx = sbox[jj];
+        const float4 bx = unpack_box(sbox[jj]);
         const bool X0 = (bx.x <= xh0) && (bx.y >= xl0), X1 = (bx.x <= xh1) && (bx.y >= xl1);
         const bool Y0 = (bx.z <= yh0) && (bx.w >= yl0), Y1 = (bx.z <= yh1) && (bx.w >= yl1);
         h0 = X0 && Y0, h1 = X1 && Y0, h2 = X0 && Y1, h3 = X1 && Y1;

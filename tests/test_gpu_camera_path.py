@@ -46,7 +46,12 @@ def test_fused_matches_oracle(S):
             np.testing.assert_allclose(times.detach().cpu().numpy(), ot.numpy(), rtol=0, atol=1e-6)
             np.testing.assert_array_equal(dT.detach().cpu().numpy(), od.numpy())
             # the module-interface forward() (move_model.py:112-135) reads the heads back from the same kernels
-            d0, d1, t0, t1 = m(info["R"], info["T"], t, stage=stage)
+            # (values only: under autograd it refuses rather than hand out graph-less tensors - forward_start_end_mid is
+            # the differentiable entry point, as on the reference's render path)
+            with pytest.raises(RuntimeError, match="no autograd graph"):
+                m(info["R"], info["T"], t, stage=stage)
+            with torch.no_grad():
+                d0, d1, t0, t1 = m(info["R"], info["T"], t, stage=stage)
             o0, o1, ot0, ot1 = camera.move_model_forward(sd, w2c[:3, :3].cpu(), w2c[:3, 3:4].cpu(), t, stage)
             np.testing.assert_allclose(d0.cpu().numpy(), o0.numpy(), rtol=0, atol=2e-6)
             np.testing.assert_allclose(d1.cpu().numpy(), o1.numpy(), rtol=0, atol=2e-6)
