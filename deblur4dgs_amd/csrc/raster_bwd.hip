@@ -72,7 +72,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // workgroup's LDS: 2 -> 1413, 3 -> 1034, 4 -> 863, 7 -> 700 us); asked for 8 the compiler fits D <= 5 in 52-64 VGPRs without
 // scratch (68 before: 7 waves): 700 -> 687 us.  The wide instantiations (D = 8, 16) keep their registers - the hint cannot be met.
 template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 5 ? 8 : 1, 8))) k_raster_bwd_q(const RasterBwdArgs a) {
+__device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
 #pragma clang fp contract(off)
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
@@ -314,6 +314,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 5
     }
   }
 }
+// Two entry points over one body: the narrow instantiations (D <= 5) are asked for 8 waves per SIMD (the hint changes the
+// scheduler's register budget); the wide ones keep the compiler's default - the hint cannot be met there and only perturbs them.
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_raster_bwd_q8(const RasterBwdArgs a) {
+  raster_bwd_q_body<D, DEPTH>(a);
+}
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
+  raster_bwd_q_body<D, DEPTH>(a);
+}
 
 #ifdef D4GS_VARIANTS
 #include "variants/raster_bwd_variants.inc"
@@ -522,7 +532,10 @@ int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, 
         return D4GS_ELAUNCH;
       }
     }
-    if (n_isect > 0) D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+    if (n_isect > 0) {
+      if constexpr (D <= 5) D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q8<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+      else D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+    }
   }
   int rc = d4gs_check_launch("k_raster_bwd");
   if (rc) return rc;

@@ -68,8 +68,20 @@ __device__ __forceinline__ float4 unpack_box(uint2 p) {
   return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
 }
 
+template <bool PACKED> struct BoxT;
+template <> struct BoxT<true> {
+  typedef uint2 type;
+  static __device__ __forceinline__ uint2 pack(float x0, float x1, float y0, float y1) { return pack_box(x0, x1, y0, y1); }
+  static __device__ __forceinline__ float4 unpack(uint2 p) { return unpack_box(p); }
+};
+template <> struct BoxT<false> {
+  typedef float4 type;
+  static __device__ __forceinline__ float4 pack(float x0, float x1, float y0, float y1) { return make_float4(x0, x1, y0, y1); }
+  static __device__ __forceinline__ float4 unpack(float4 p) { return p; }
+};
+
 template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 4 ? 8 : 1, 8))) k_raster_fwd_r(const RasterFwdArgs a) {
+__device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 #pragma clang fp contract(off)
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
@@ -78,7 +90,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 4
                                            // batches keep 4+ workgroups per CU (measured 17-ch: 0.45 -> 0.42 ms)
   __shared__ float4 sg0[FB];
   __shared__ float4 sg1[FB];
-  __shared__ uint2 sbox[FB];  // tight box in tile-local pixels as 4 x f16 (widened: conservative), see pack_box
+  __shared__ typename BoxT<(DV <= 1)>::type sbox[FB];  // tight box in tile-local pixels
   __shared__ float4 scol[FB * DV];
   __shared__ unsigned char slist[4 * 4 * FB];  // [wave][row][position]
 
@@ -96,9 +108,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 4
   const bool inside = x < a.width && y < a.height;
   const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
   // pixel-centre extents of the two block columns / block rows of this quadrant
-  // (tile-local: the staged boxes are relative to the tile origin)
-  const float tx0f = (float)(tx * D4GS_TILE), ty0f = (float)(ty * D4GS_TILE);
-  const float qlx = (float)((wv & 1) * 8), qly = (float)((wv >> 1) * 8);
+  // (packed boxes are relative to the tile origin; the unpacked ones stay in image coordinates)
+  constexpr bool PB = DV <= 1;  // boxes packed as 4 x f16 where that buys the 8th workgroup per CU (see pack_box)
+  const float tx0f = PB ? (float)(tx * D4GS_TILE) : 0.f, ty0f = PB ? (float)(ty * D4GS_TILE) : 0.f;
+  const float qlx = (float)qx0 - tx0f, qly = (float)qy0 - ty0f;
   const float xl0 = qlx + 0.5f, xh0 = qlx + 3.5f, xl1 = qlx + 4.5f, xh1 = qlx + 7.5f;
   const float yl0 = qly + 0.5f, yh0 = qly + 3.5f, yl1 = qly + 4.5f, yh1 = qly + 7.5f;
   unsigned char *wlist = slist + wv * 4 * FB;
@@ -129,7 +142,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 4
         ex = sqrtf(2.f * tau * q1.z * idet) + 1e-3f;
         ey = sqrtf(2.f * tau * q1.x * idet) + 1e-3f;
       }
-      sbox[tid] = ex < 0.f ? pack_box(1e30f, -1e30f, 1e30f, -1e30f) : pack_box(q0.x - ex - tx0f, q0.x + ex - tx0f, q0.y - ey - ty0f, q0.y + ey - ty0f);
+      sbox[tid] = ex < 0.f ? BoxT<PB>::pack(1e30f, -1e30f, 1e30f, -1e30f) : BoxT<PB>::pack(q0.x - ex - tx0f, q0.x + ex - tx0f, q0.y - ey - ty0f, q0.y + ey - ty0f);
       const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
 #pragma unroll
       for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
@@ -143,7 +156,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 4
       const int jj = k * 64 + lane;
       bool h0 = false, h1 = false, h2 = false, h3 = false;
       if (jj < nb) {
-        const float4 bx = unpack_box(sbox[jj]);
+        const float4 bx = BoxT<PB>::unpack(sbox[jj]);
         const bool X0 = (bx.x <= xh0) && (bx.y >= xl0), X1 = (bx.x <= xh1) && (bx.y >= xl1);
         const bool Y0 = (bx.z <= yh0) && (bx.w >= yl0), Y1 = (bx.z <= yh1) && (bx.w >= yl1);
         h0 = X0 && Y0, h1 = X1 && Y0, h2 = X0 && Y1, h3 = X1 && Y1;
@@ -207,6 +220,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D <= 4
     if (DEPTH) o[D] = a.ed ? acc[D] / fmaxf(al, 1e-10f) : acc[D];
   }
 }
+// Two entry points over one body: the narrow instantiations (D <= 4) are asked for 8 waves per SIMD (the hint changes the
+// scheduler's register budget); the wide ones keep the compiler's default - the hint cannot be met there and only perturbs them.
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_raster_fwd_r8(const RasterFwdArgs a) {
+  raster_fwd_r_body<D, DEPTH>(a);
+}
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
+  raster_fwd_r_body<D, DEPTH>(a);
+}
 
 template <int D, bool DEPTH>
 int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
@@ -224,7 +247,8 @@ int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
     return d4gs_check_launch("k_raster_fwd_q");
   }
 #endif
-  D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+  if constexpr (D <= 4) D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r8<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+  else D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
   return d4gs_check_launch("k_raster_fwd_r");
 }
 
