@@ -355,6 +355,7 @@ struct GatherArgs {
 // isect_grad: the wave streams it into LDS with coalesced loads and every lane then sums its own rows from there, in
 // the same k order as a direct read (bit-identical).  Spans longer than the LDS budget (wide splats) take several chunks.
 constexpr int GATHER_THREADS = 128, GATHER_ROWS = 192;  // rows of LDS per wave
+constexpr int GATHER_SC = 1024;                         // rows per super-chunk of the cooperative sparse path (16 flags per lane)
 template <int D, bool DEPTH, bool SPARSE>
 __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
@@ -362,6 +363,11 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   constexpr int R = 6 + NCH;
   __shared__ __attribute__((aligned(16))) float stage[(GATHER_THREADS / 64) * GATHER_ROWS * R];
   __shared__ uint32_t slive[SPARSE ? (GATHER_THREADS / 64) * 64 : 1];  // flags of a chunk as 4-byte words (<= GATHER_ROWS + 3 bytes)
+  // cooperative sparse path (super-chunks of SC rows): the flags, the exclusive live-row count in front of every 16-row group
+  // and the compacted list of live rows
+  __shared__ __attribute__((aligned(16))) uint32_t sflag[SPARSE ? (GATHER_THREADS / 64) * (GATHER_SC / 4) : 1];
+  __shared__ uint16_t sgrp[SPARSE ? (GATHER_THREADS / 64) * (GATHER_SC / 16 + 1) : 1];
+  __shared__ uint16_t slist[SPARSE ? (GATHER_THREADS / 64) * GATHER_SC : 1];
   static_assert(GATHER_ROWS + 6 <= 256, "one flag word per lane");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,7 +409,107 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
     // GATHER_ROWS keeps the later chunks aligned) and the last word may carry up to 3 floats of the next row.
     constexpr int APER = (R % 4 == 0) ? 1 : (R % 2 == 0) ? 2 : 4;
     static_assert(GATHER_ROWS % APER == 0 && (GATHER_ROWS * R) % 4 == 0, "chunks must start on 16-byte words");
-    for (int cb = base & ~(APER - 1); cb < endl; cb += GATHER_ROWS) {
+    int cb0 = base & ~(APER - 1), skip_to = 0;
+    if constexpr (SPARSE) {
+      // Occluded / large-footprint scenes: most rows of the span were never written.  A super-chunk of SC rows is handled
+      // by the whole wave: (1) every lane fetches 16 flag bytes, (2) a wave scan compacts the LIVE rows' indices into a list
+      // (row order = instance-major, ascending k), (3) the wave fetches those rows 64 at a time - one row per lane, all
+      // loads in flight together - into the LDS stage, (4) every lane adds ITS rows from the stage: their positions are the
+      // live-row counts in front of its first / behind its last row (group prefix + popcount of the group's flags).  Same
+      // k order as the streaming path -> the same bits.  Super-chunks that are >= 1 / 4 live, or hold more live rows than
+      // the stage, take the streaming path below.
+      uint32_t *myflag = sflag + wv * (GATHER_SC / 4);
+      uint16_t *mygrp = sgrp + wv * (GATHER_SC / 16 + 1);
+      uint16_t *mylist = slist + wv * GATHER_SC;
+      const int rows4 = (int)((a.rows + 3) & ~(int64_t)3);  // the flag buffer is padded to whole words
+      for (int sb = base & ~15; sb < endl;) {
+        const int se = min(sb + GATHER_SC, endl);
+        // (1) 16 flags of rows sb + 16 lane .. + 15 (words past the span / the buffer read as 0)
+        uint32_t f[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const int r0 = sb + 16 * lane + 4 * w;
+          f[w] = (r0 < se && r0 < rows4) ? reinterpret_cast<const uint32_t *>(a.live)[r0 >> 2] & 0x01010101u : 0u;
+        }
+        // rows in front of the span start (sb rounds down) or behind its end (a word may straddle it) belong to other
+        // waves: drop their flags
+        if (sb < base || (se & 3)) {  // wave-uniform
+#pragma unroll
+          for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const int r = sb + 16 * lane + 4 * w + b;
+              if (r < base || r >= se) f[w] &= ~(1u << (8 * b));
+            }
+        }
+        const int cnt16 = __popc(f[0]) + __popc(f[1]) + __popc(f[2]) + __popc(f[3]);
+        int incl = cnt16;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o);
+          if (lane >= o) incl += t;
+        }
+        const int L = __shfl(incl, 63);  // live rows of the super-chunk (wave-uniform)
+        if (L == 0) {
+          sb = skip_to = se;
+          continue;
+        }
+        if (L * 2 > se - sb) break;  // at least half of the rows are live: stream the rest of the span
+        const int excl = incl - cnt16;
+        *reinterpret_cast<uint4 *>(myflag + 4 * lane) = make_uint4(f[0], f[1], f[2], f[3]);
+        mygrp[lane] = (uint16_t)excl;
+        if (lane == 63) mygrp[64] = (uint16_t)L;
+        // (2) the list
+        int pos = excl;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if (f[w] & (1u << (8 * b))) mylist[pos++] = (uint16_t)(16 * lane + 4 * w + b);
+        __builtin_amdgcn_wave_barrier();
+        // (3) + (4) in rounds of at most GATHER_ROWS live rows (the stage): one live row per lane and iteration, then
+        // every lane adds the rows of the round that are its own - their list positions are the live-row counts in front of
+        // its first / behind its last row (group prefix + popcount of the group's flags); rounds ascend -> ascending k
+        const int k0 = max(off, sb), k1 = min(off + cnt, se);
+        int p0 = 0, p1 = 0;
+        if (k0 < k1) {
+          auto before = [&](int k) -> int {  // live rows of the super-chunk in front of row k (sb <= k <= se)
+            const int q = k - sb, gq = q >> 4, w = (q >> 2) & 3, b = q & 3;
+            if (gq >= 64) return (int)mygrp[64];
+            int n = mygrp[gq];
+            const uint32_t *fw = myflag + 4 * gq;
+            for (int i = 0; i < w; i++) n += (int)__popc(fw[i]);
+            return n + (int)__popc(fw[w] & ((1u << (8 * b)) - 1u));
+          };
+          p0 = before(k0), p1 = before(k1);
+        }
+        for (int rb = 0; rb < L; rb += GATHER_ROWS) {
+          const int re = min(rb + GATHER_ROWS, L);
+          for (int e = rb + lane; e < re; e += 64) {
+            const float *row = a.isect_grad + (size_t)(sb + mylist[e]) * R;
+            float *dst = mine + (e - rb) * R;
+            if constexpr (R % 2 == 0) {
+#pragma unroll
+              for (int r = 0; r < R; r += 2) *reinterpret_cast<float2 *>(dst + r) = *reinterpret_cast<const float2 *>(row + r);
+            } else {
+#pragma unroll
+              for (int r = 0; r < R; r++) dst[r] = row[r];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          const int q0 = max(p0, rb), q1 = min(p1, re);
+          const float *row = mine + (q0 - rb) * R;
+          for (int pp = q0; pp < q1; pp++, row += R) {
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] += row[r];
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        sb = skip_to = se;
+      }
+      cb0 = max(cb0, skip_to & ~(APER - 1));  // rows below skip_to are done: the loop below starts at their (aligned) end
+    }
+    for (int cb = cb0; cb < endl; cb += GATHER_ROWS) {
       const int ce = min(cb + GATHER_ROWS, endl);
       // the chunk's flag bytes, fetched as words BEFORE the rows so that their latency hides behind the row stream
       const int fb = cb & ~3;
@@ -419,7 +525,7 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
         if (nlive * 8 < ce - cb) {  // wave-uniform
           mylive32[lane] = fl;
           __builtin_amdgcn_wave_barrier();
-          const int k0 = max(off, cb), k1 = min(off + cnt, ce);
+          const int k0 = max(max(off, cb), skip_to), k1 = min(off + cnt, ce);
           for (int k = k0; k < k1; k++) {
             if (!mylive[k - fb]) continue;
             const float *row = a.isect_grad + (size_t)k * R;
@@ -448,7 +554,7 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
       if (tail0 + lane < tail1) mine[tail0 + lane] = a.isect_grad[(size_t)cb * R + tail0 + lane];
       if constexpr (SPARSE) mylive32[lane] = fl;
       __builtin_amdgcn_wave_barrier();
-      const int k0 = max(off, cb), k1 = min(off + cnt, ce);
+      const int k0 = max(max(off, cb), skip_to), k1 = min(off + cnt, ce);
       const float *row = mine + (k0 - cb) * R;
       for (int k = k0; k < k1; k++, row += R) {
         if constexpr (SPARSE)

@@ -14,6 +14,8 @@ There is no eager / CPU fallback: tensors must live on a ROCm device.
 """
 from __future__ import annotations
 
+import os
+
 import collections
 import ctypes as C
 import threading
@@ -95,8 +97,11 @@ class State:
     v_means2d: object = None
 
 
-BWD_ROWS = "auto"  # "auto" | "dense" | "sparse": gradient-row mode of the composite backward (D4gsRasterGrads.row_mode);
-#                    "auto" lets the library choose from the list capacity per instance.  Module-level so tests can force it.
+# "auto" | "dense" | "sparse": gradient-row mode of the composite backward (D4gsRasterGrads.row_mode); "auto" lets the library
+# choose from the list capacity per instance.  Module-level so tests can force it; D4GS_BWD_ROWS (read once, at import) runs a whole
+# test session in one mode.
+BWD_ROWS = os.environ.get("D4GS_BWD_ROWS", "auto")
+assert BWD_ROWS in ("auto", "dense", "sparse"), f"D4GS_BWD_ROWS={BWD_ROWS!r}"
 
 SUPPORTED_D = (1, 2, 3, 4, 5, 8, 16)  # colour-channel instantiations of the composite kernels (+ optional depth)
 
