@@ -127,7 +127,7 @@ int d4gs_query_sizes(const D4gsDims *d, D4gsSizes *z) {
   const int64_t nch = d->D + (d->depth_mode != D4GS_DEPTH_NONE ? 1 : 0), DP = (d->D + 3) & ~3;
   z->means2d = SN * 2, z->depths = SN, z->conics = SN * 3, z->radii = SN, z->opac_act = N, z->ctab = N * DP;
   z->geom = SN * D4GS_GEOM_STRIDE, z->tile_rects = SN * 2, z->tiles_touched = SN, z->isect_offsets = SN;
-  z->tile_counts = 2 * S * tw * th, z->tile_offsets = S * tw * th + 1, z->n_isect = 2;
+  z->tile_counts = 2 * S * tw * th, z->tile_offsets = S * tw * th + 1, z->n_isect = 4;
   z->scan_ws = (int64_t)d4gs_scan_ws_elems(SN);
   z->render_colors = S * H * W * nch, z->render_alphas = S * H * W, z->last_ids = S * H * W, z->final_T = S * H * W;
   z->isect_grad_row = 6 + nch;

@@ -29,7 +29,8 @@ struct RasterFwdArgs {
   float *alphas;   // [S,H,W]
   int32_t *last_ids;
   float *final_T;
-  const int64_t *n_dev;  // device {total, longest list} vs the capacity the lists were sized for (see binning.hip)
+  int64_t *n_dev;  // device {total, longest list, live rows, -}: [0], [1] vs the capacity the lists were sized for (see binning.hip);
+                   // [2] += this tile's list entries up to its last contributor (the rows the backward replays)
   int64_t cap, max_hint;
 };
 
@@ -119,7 +120,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 
   float T = 1.f, acc[NCH];
   int last = 0;
-  bool done = !inside;
+  bool done = !inside, has_last = false;
 #pragma unroll
   for (int c = 0; c < NCH; c++) acc[c] = 0.f;
 
@@ -206,8 +207,21 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
      if (__all(done)) break;
     }
     last = lastj >= 0 ? b + lastj : last;  // list index of the batch's last contributor, formed once per batch
+    has_last = has_last || lastj >= 0;
   }
 
+  {  // live rows of the tile: one atomic per workgroup (sizes the backward's row mode, include/d4gs.h)
+    __shared__ int slive_hi[4];
+    int hi = (inside && last >= start && has_last) ? last : start - 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) hi = max(hi, __shfl_xor(hi, o));
+    if (lane == 0) slive_hi[wv] = hi;
+    __syncthreads();
+    if (tid == 0 && a.n_dev) {
+      const int h = max(max(slive_hi[0], slive_hi[1]), max(slive_hi[2], slive_hi[3]));
+      if (h >= start) atomicAdd(reinterpret_cast<unsigned long long *>(a.n_dev + 2), (unsigned long long)(h - start + 1));
+    }
+  }
   if (inside) {
     const size_t pix = ((size_t)s * a.height + y) * a.width + x;
     const float al = 1.f - T;

@@ -165,11 +165,40 @@ def _guess_put(key, val):
             _SIZE_GUESS.popitem(last=False)
 
 
+# Live fraction of the intersection lists, per size key: the forward composite counts the list entries at or in front of
+# their tile's last contributor (D4gsProjOut.n_isect[2]) - the rows the backward will replay.  Occluded / large-footprint
+# scenes replay a small part of their lists and want the backward's SPARSE row mode, whatever their rows per instance
+# (cfg2 with 2x splats: 16 % live at 3.2 rows per instance, sparse 7 % faster; cfg3: 91 % live at 4.2, dense 5 % faster).  The
+# count arrives with the list sizes, so the choice is made from the previous render of that shape.
+_LIVE_FRAC: collections.OrderedDict = collections.OrderedDict()
+LIVE_SPARSE_BELOW = 0.5
+
+
+def _live_put(key, live, n, nchunks):
+    with _SIZE_LOCK:
+        _LIVE_FRAC[key] = live / (max(n, 1) * max(nchunks, 1))  # every channel chunk composites (and counts) the lists once
+        _LIVE_FRAC.move_to_end(key)
+        while len(_LIVE_FRAC) > _SIZE_GUESS_MAX:
+            _LIVE_FRAC.popitem(last=False)
+
+
+def row_mode_for(cfg, dev):
+    """D4gsRasterGrads.row_mode for a render of this shape: the forced mode, or - "auto" - sparse / dense from the live
+    fraction its previous render measured, or the library's capacity heuristic while there is no measurement."""
+    if BWD_ROWS != "auto":
+        return {"dense": L.ROWS_DENSE, "sparse": L.ROWS_SPARSE}[BWD_ROWS]
+    with _SIZE_LOCK:
+        f = _LIVE_FRAC.get(_size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height))
+    if f is None:
+        return L.ROWS_AUTO
+    return L.ROWS_SPARSE if f < LIVE_SPARSE_BELOW else L.ROWS_DENSE
+
+
 _DEFERRED: dict = {}  # size key -> [(pinned int64[2], event, capacity, max-tile hint), ...]: EVERY unchecked render of that
 #                       shape, oldest first (a training step issues several renders of one shape before any count lands)
 
 
-_PINNED_FREE: list = []  # pinned int64[2] buffers whose deferred count has been consumed (guarded by _SIZE_LOCK)
+_PINNED_FREE: list = []  # pinned int64[4] buffers whose deferred count has been consumed (guarded by _SIZE_LOCK)
 
 
 def _deferred_poll(key, block: bool = False):
@@ -186,9 +215,11 @@ def _deferred_poll(key, block: bool = False):
         if not recs:
             _DEFERRED.pop(key, None)
     last, bad = None, None
-    for host_n, ev, cap, hint in ready:
+    for host_n, ev, cap, hint, nchunks in ready:
         ev.synchronize()
-        n, max_tile = host_n.tolist()
+        n, max_tile, live, _ = host_n.tolist()
+        if n <= cap and not (hint > 0 and max_tile > hint):  # (an overflowed render composited nothing)
+            _live_put(key, live, n, nchunks)
         with _SIZE_LOCK:  # the copy has landed and been read: the pinned pair can carry the next count
             if len(_PINNED_FREE) < 64:
                 _PINNED_FREE.append(host_n)
@@ -228,7 +259,7 @@ def _pinned_counts(dev):
         if k not in _PINNED:
             if len(_PINNED) > 256:
                 _PINNED.clear()
-            _PINNED[k] = torch.empty(2, dtype=torch.int64).pin_memory()
+            _PINNED[k] = torch.empty(4, dtype=torch.int64).pin_memory()
         return _PINNED[k]
 
 
@@ -274,7 +305,7 @@ class ProjectFn(torch.autograd.Function):
             tiles_touched=torch.empty(S * N, **i32),
             isect_offsets=torch.empty(S * N, **i32), tile_ranks=None,
             tile_counts=torch.empty(2 * S * tw * th, **i32),
-            tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(2, dtype=torch.int64, device=dev),
+            tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(4, dtype=torch.int64, device=dev),
             scan_ws=torch.empty(lib.d4gs_scan_ws_elems(S * N), **i32),
         )
         dims = cfg.dims()
@@ -372,12 +403,12 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
                 with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
                     host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
                 if host_n is None:
-                    host_n = torch.empty(2, dtype=torch.int64).pin_memory()
+                    host_n = torch.empty(4, dtype=torch.int64).pin_memory()
                 host_n.copy_(n_isect_dev(), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 with _SIZE_LOCK:
-                    _DEFERRED.setdefault(key, []).append((host_n, ev, guess[0], guess[1]))
+                    _DEFERRED.setdefault(key, []).append((host_n, ev, guess[0], guess[1], len(channel_chunks(cfg.D))))
             _SIZE_STATS["calls"] += 1
             return guess
     # The list sizes live on the device.  Read them back through pinned memory; when a previous call of the same
@@ -393,7 +424,9 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
     ev = torch.cuda.Event()
     ev.record()
     ev.synchronize()
-    n, max_tile = host_n.tolist()
+    n, max_tile, live, _ = host_n.tolist()
+    if guess is not None and n <= guess[0] and not (guess[1] > 0 and max_tile > guess[1]):
+        _live_put(key, live, n, len(channel_chunks(cfg.D)))  # (the launch in front of this readback composited the frame)
     if guess is None or n > guess[0] or (guess[1] > 0 and max_tile > guess[1]):
         if guess is not None:
             _SIZE_STATS["relaunched"] += 1
@@ -473,7 +506,7 @@ class RasterFn(torch.autograd.Function):
         isect.n_isect, isect.max_tile_count = st.n_isect, st.max_tile
         ras = L.fill(L.Raster(), **rst)
         rg = L.fill(L.RasterGrads(), **g)
-        rg.row_mode = {"auto": L.ROWS_AUTO, "dense": L.ROWS_DENSE, "sparse": L.ROWS_SPARSE}[BWD_ROWS]
+        rg.row_mode = row_mode_for(cfg, dev)
         if cfg.control_stats is not None:  # fused statistics: the gather epilogue owns v_means2d and reads radii
             cs = _check_stats(cfg.control_stats, N)
             rg.stats_grad_norm_acc, rg.stats_vis_count = L.ptr(cs["xys_grad_norm_acc"]), L.ptr(cs["vis_count"])
@@ -511,7 +544,7 @@ class FrameFn(torch.autograd.Function):
         io = dict(blended=torch.empty(H, W, NCH, **f32) if blended else None, acc=torch.empty(H, W, **f32) if blended else None,
                   renders=torch.empty(S, H, W, NCH, **f32), alphas=torch.empty(S, H, W, **f32),
                   means2d=torch.empty(S, N, 2, **f32), radii=torch.empty(S, N, dtype=torch.int32, device=dev),
-                  n_isect=torch.empty(2, dtype=torch.int64, device=dev), background=_f32c(background))
+                  n_isect=torch.empty(4, dtype=torch.int64, device=dev), background=_f32c(background))
         dims = cfg.dims()
         pin = L.fill(L.ProjIn(), **st.proj_in)
         fio = L.fill(L.FrameIO(), **io)
@@ -577,7 +610,7 @@ class FrameFn(torch.autograd.Function):
         fg = L.FrameGrads()
         fg.v_blended, fg.v_acc, fg.v_renders, fg.v_alphas = L.ptr(v_blended), L.ptr(v_acc), L.ptr(v_renders), L.ptr(v_alphas)
         fg.v_means2d = L.ptr(v_m2d)
-        fg.row_mode = {"auto": L.ROWS_AUTO, "dense": L.ROWS_DENSE, "sparse": L.ROWS_SPARSE}[BWD_ROWS]
+        fg.row_mode = row_mode_for(cfg, dev)
         if cfg.control_stats is not None:
             cs = _check_stats(cfg.control_stats, cfg.N)
             fg.stats_grad_norm_acc, fg.stats_vis_count = L.ptr(cs["xys_grad_norm_acc"]), L.ptr(cs["vis_count"])

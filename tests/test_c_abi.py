@@ -32,7 +32,7 @@ def test_exports_match_header(lib):
 def test_version_and_error_paths(lib):
     from deblur4dgs_amd import _lib as L
 
-    assert lib.d4gs_version() == 300
+    assert lib.d4gs_version() == 301
     lib.d4gs_last_error.restype = C.c_char_p
     assert lib.d4gs_project_fwd(None, None, None, None) == -1  # D4GS_EINVAL, no HIP call made
     assert b"NULL" in lib.d4gs_last_error()
@@ -108,7 +108,7 @@ def test_query_sizes_is_a_pure_host_call(lib):
     assert (z.means2d, z.depths, z.conics, z.radii) == (SN * 2, SN, SN * 3, SN)
     assert (z.opac_act, z.ctab, z.geom) == (1000, 1000 * 4, SN * L.GEOM_STRIDE)
     assert (z.tile_rects, z.tiles_touched, z.isect_offsets) == (SN * 2, SN, SN)
-    assert (z.tile_counts, z.tile_offsets, z.n_isect) == (2 * 8 * tw * th, 8 * tw * th + 1, 2)
+    assert (z.tile_counts, z.tile_offsets, z.n_isect) == (2 * 8 * tw * th, 8 * tw * th + 1, 4)
     assert z.render_colors == 8 * 50 * 100 * 4 and z.render_alphas == z.last_ids == z.final_T == 8 * 50 * 100
     assert z.isect_grad_row == 6 + 4
     lib.d4gs_scan_ws_elems.restype = C.c_size_t
