@@ -208,6 +208,30 @@ def _stats(ts, N, S):
             "instances_per_s": N * S / statistics.median(ts)}
 
 
+def _cpu_twin_cfg1(iters=5):
+    """BASELINE config 1 through the PRODUCT's CPU twin (d4gs_forward_cpu / d4gs_backward_cpu, scalar fp32, one thread) -
+    reported beside the oracle's legs; it is product code, so it is not the checker and not `value`."""
+    from deblur4dgs_amd.cpu_twin import render_exposure_cpu
+
+    N, G, K, S, W, H = CONFIGS["cfg1"]
+    sc = scene_of("cfg1", channels=3)
+    keys = ("means", "quats", "scales", "colors", "opacities")
+    P = {k: sc[k].float().clone().requires_grad_() for k in keys}
+    ts = []
+    for _ in range(iters):
+        for v in P.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        r = render_exposure_cpu(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], 3, None, None, None, None,
+                                sc["RTs"].float(), sc["viewmat"].float(), sc["K"].float(), W, H, background=torch.ones(3),
+                                return_depth=True)
+        (r["blended"].sum() + r["acc"].sum()).backward()
+        ts.append(time.perf_counter() - t0)
+    out = _stats(ts, N, S)
+    out.update(cores=1, entry="d4gs_forward_cpu + d4gs_backward_cpu (csrc/cpu_twin.hip)", config="cfg1")
+    return out
+
+
 def cpu_baseline(name, channels, full=False):
     """The build's CPU restatement of the path (the reference has NO CPU path: flow3d/scene_model.py:36,360), timed on
     this box's host cores as BASELINE.md section 3 plans: the same seeded frame, forward + backward, (i) through the
@@ -241,6 +265,7 @@ def cpu_baseline(name, channels, full=False):
         if n_isect is not None:
             r["n_isect"] = n_isect
         out["runs"][f"{cfgname}/{impl}"] = r
+    out["product_cpu_twin"] = _cpu_twin_cfg1()
     head = out["runs"][f"{name}/scalar_c"]
     N, G, K, S, W, H = CONFIGS[name]
     out.update(value=head["gaussians_per_s"], cores=head["cores"],

@@ -391,6 +391,14 @@ int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO 
                   const D4gsLeafGrads *leaf /* .partials is ignored: it lives in the workspace */, void *workspace,
                   size_t ws_bytes, int64_t isect_capacity, int64_t max_tile_hint, void *stream);
 
+/* CPU twins of the two calls above (BASELINE config 1, the CPU-runnable plumbing case): the same arithmetic rules
+ * and the same structs with every pointer a HOST pointer; no stream, no workspace (scratch is allocated and freed inside; the
+ * backward re-runs the forward), io->n_isect [4] host.  Scalar fp32, one thread - a separate entry point for hosts without a
+ * GPU, never a fallback: d4gs_forward and the Python seams still refuse CPU tensors.  csrc/cpu_twin.hip. */
+int d4gs_forward_cpu(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io);
+int d4gs_backward_cpu(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, const D4gsFrameGrads *g,
+                      const D4gsLeafGrads *leaf);
+
 /* Exposure sharding (one process per GPU): the same blend when this process holds only the sub-samples
  * s_first + j * s_stride, j < S_local, of the S_total.  Collectives stay with the caller (RCCL through torch.distributed):
  *   forward : partial_fwd -> all-reduce SUM of part [P,C+1] (colours + alpha) and MAX of cand [P,npol] (the max / min

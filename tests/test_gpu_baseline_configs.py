@@ -1,8 +1,8 @@
 """BASELINE.json `configs[0]` ("10k static Gaussians, 1 cam, 288x512, N_exposure=1") on its exact workload, in full:
 the HIP path (raw leaves -> activations -> projection -> binning -> composite -> S=1 blend, forward and backward)
 against the fp64 torch oracle - the image, alpha and EVERY leaf gradient incl. viewmat.  The reference has no CPU
-renderer (flow3d/scene_model.py:36 hard `.cuda()`, gsplat is CUDA-only) and this tier forbids a product path through
-the oracle, so cfg1's "plumbing" is exercised on the device against the CPU restatement rather than by a CPU twin.
+renderer (flow3d/scene_model.py:36 hard `.cuda()`, gsplat is CUDA-only); cfg1 runs here on the device against the CPU
+restatement, and on the product's CPU twin (d4gs_forward_cpu / d4gs_backward_cpu) in tests/test_cpu_twin.py without a GPU.
 (cfg2 / cfg3 / cfg5: tests/test_gpu_fullsize_properties.py; cfg4: tests/test_gpu_parallel.py.)"""
 import pytest
 import torch
