@@ -96,7 +96,7 @@ RAW_PARAMS, RAW_COLORS, EXACT_CULL = 1, 2, 4
 DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
 ROWS_AUTO, ROWS_DENSE, ROWS_SPARSE = 0, 1, 2
 TILE = 16
-VERSION = 301  # D4GS_VERSION of include/d4gs.h
+VERSION = 302  # D4GS_VERSION of include/d4gs.h
 GEOM_STRIDE = 8
 
 EXPORTS = (

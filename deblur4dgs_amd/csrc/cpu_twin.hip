@@ -337,7 +337,8 @@ void forward_impl(const D4gsDims &d, const D4gsProjIn &in, const D4gsFrameIO &io
   // composite, front to back
   const int NCH = f.NCH;
   f.last.assign((size_t)S * H * W, -1), f.finalT.assign((size_t)S * H * W, 1.f);
-  long long live = 0;
+  long long live = 0, sampled = 0;  // the same tile sample as the device path: every ceil(tiles / 128)-th tile
+  const int lstride = (S * n_tiles + 127) >> 7;
   std::vector<float> acc(std::max(NCH, 1));
   for (int s = 0; s < S; s++)
     for (int tyi = 0; tyi < f.th; tyi++)
@@ -372,9 +373,9 @@ void forward_impl(const D4gsDims &d, const D4gsProjIn &in, const D4gsFrameIO &io
             for (int c = 0; c < D; c++) o[c] = acc[c] + (io.background ? T * io.background[c] : 0.f);
             if (NCH > D) o[D] = d.depth_mode == D4GS_DEPTH_ED ? acc[D] / fmaxf(al, 1e-10f) : acc[D];
           }
-        live += tile_hi - b0 + 1;
+        if (t % lstride == 0) sampled += b1 - b0, live += tile_hi - b0 + 1;
       }
-  if (io.n_isect) io.n_isect[0] = n_isect, io.n_isect[1] = longest, io.n_isect[2] = live, io.n_isect[3] = 0;
+  if (io.n_isect) io.n_isect[0] = n_isect, io.n_isect[1] = longest, io.n_isect[2] = sampled, io.n_isect[3] = live;  // D4gsProjOut.n_isect
   // blend (scene_model.py:386-397 incl. the in-place max / min quirk: candidates raw_0 .. raw_{S-2} and the mean)
   if (io.blended) {
     const size_t P = (size_t)H * W, PC = P * NCH;

@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(1024) k_scan_single(const ScanJob ja, const Sc
   }
   if (threadIdx.x == 0) {
     if (write_last) out[n] = (int)carry;
-    if (total64) total64[0] = carry, total64[2] = 0, total64[3] = 0;  // (D4gsProjOut.n_isect[2]: live rows, counted by the forward composite)
+    if (total64) total64[0] = carry, total64[2] = 0, total64[3] = 0;  // ([2], [3]: the forward composite's live-row sample)
     if (max64) *max64 = smax;
   }
 }

@@ -29,8 +29,8 @@ struct RasterFwdArgs {
   float *alphas;   // [S,H,W]
   int32_t *last_ids;
   float *final_T;
-  int64_t *n_dev;  // device {total, longest list, live rows, -}: [0], [1] vs the capacity the lists were sized for (see binning.hip);
-                   // [2] += this tile's list entries up to its last contributor (the rows the backward replays)
+  int64_t *n_dev;  // device {total, longest list, sampled entries, sampled live entries}: [0], [1] vs the capacity the lists were
+                   // sized for (see binning.hip); [2], [3]: this kernel's live-row sample
   int64_t cap, max_hint;
 };
 
@@ -210,16 +210,20 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     has_last = has_last || lastj >= 0;
   }
 
-  {  // live rows of the tile: one atomic per workgroup (sizes the backward's row mode, include/d4gs.h)
+  // live-row sample (include/d4gs.h, D4gsProjOut.n_isect[2..3]): every `stride`-th tile adds its list length and the entries
+  // up to its last contributor - at most 128 tiles, so the device-scope atomics never queue up
+  const int lstride = (n_tiles + 127) >> 7;
+  if (a.n_dev && t % lstride == 0) {  // workgroup-uniform
     __shared__ int slive_hi[4];
     int hi = (inside && last >= start && has_last) ? last : start - 1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) hi = max(hi, __shfl_xor(hi, o));
     if (lane == 0) slive_hi[wv] = hi;
     __syncthreads();
-    if (tid == 0 && a.n_dev) {
+    if (tid == 0) {
       const int h = max(max(slive_hi[0], slive_hi[1]), max(slive_hi[2], slive_hi[3]));
-      if (h >= start) atomicAdd(reinterpret_cast<unsigned long long *>(a.n_dev + 2), (unsigned long long)(h - start + 1));
+      atomicAdd(reinterpret_cast<unsigned long long *>(a.n_dev + 2), (unsigned long long)(end - start));
+      atomicAdd(reinterpret_cast<unsigned long long *>(a.n_dev + 3), (unsigned long long)(h - start + 1));
     }
   }
   if (inside) {

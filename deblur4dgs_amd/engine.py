@@ -166,7 +166,7 @@ def _guess_put(key, val):
 
 
 # Live fraction of the intersection lists, per size key: the forward composite counts the list entries at or in front of
-# their tile's last contributor (D4gsProjOut.n_isect[2]) - the rows the backward will replay.  Occluded / large-footprint
+# their tile's last contributor, on a fixed sample of tiles (D4gsProjOut.n_isect[2..3]) - the rows the backward will replay.  Occluded / large-footprint
 # scenes replay a small part of their lists and want the backward's SPARSE row mode, whatever their rows per instance
 # (cfg2 with 2x splats: 16 % live at 3.2 rows per instance, sparse 7 % faster; cfg3: 91 % live at 4.2, dense 5 % faster).  The
 # count arrives with the list sizes, so the choice is made from the previous render of that shape.
@@ -174,9 +174,11 @@ _LIVE_FRAC: collections.OrderedDict = collections.OrderedDict()
 LIVE_SPARSE_BELOW = 0.5
 
 
-def _live_put(key, live, n, nchunks):
+def _live_put(key, live, sampled):
+    if sampled <= 0:  # nothing sampled (empty lists): no evidence, keep what is known
+        return
     with _SIZE_LOCK:
-        _LIVE_FRAC[key] = live / (max(n, 1) * max(nchunks, 1))  # every channel chunk composites (and counts) the lists once
+        _LIVE_FRAC[key] = live / sampled  # (a wide render's channel chunks count the same tiles once each: the ratio is unchanged)
         _LIVE_FRAC.move_to_end(key)
         while len(_LIVE_FRAC) > _SIZE_GUESS_MAX:
             _LIVE_FRAC.popitem(last=False)
@@ -215,11 +217,11 @@ def _deferred_poll(key, block: bool = False):
         if not recs:
             _DEFERRED.pop(key, None)
     last, bad = None, None
-    for host_n, ev, cap, hint, nchunks in ready:
+    for host_n, ev, cap, hint in ready:
         ev.synchronize()
-        n, max_tile, live, _ = host_n.tolist()
+        n, max_tile, sampled, live = host_n.tolist()
         if n <= cap and not (hint > 0 and max_tile > hint):  # (an overflowed render composited nothing)
-            _live_put(key, live, n, nchunks)
+            _live_put(key, live, sampled)
         with _SIZE_LOCK:  # the copy has landed and been read: the pinned pair can carry the next count
             if len(_PINNED_FREE) < 64:
                 _PINNED_FREE.append(host_n)
@@ -408,7 +410,7 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
                 ev = torch.cuda.Event()
                 ev.record()
                 with _SIZE_LOCK:
-                    _DEFERRED.setdefault(key, []).append((host_n, ev, guess[0], guess[1], len(channel_chunks(cfg.D))))
+                    _DEFERRED.setdefault(key, []).append((host_n, ev, guess[0], guess[1]))
             _SIZE_STATS["calls"] += 1
             return guess
     # The list sizes live on the device.  Read them back through pinned memory; when a previous call of the same
@@ -424,9 +426,9 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
     ev = torch.cuda.Event()
     ev.record()
     ev.synchronize()
-    n, max_tile, live, _ = host_n.tolist()
+    n, max_tile, sampled, live = host_n.tolist()
     if guess is not None and n <= guess[0] and not (guess[1] > 0 and max_tile > guess[1]):
-        _live_put(key, live, n, len(channel_chunks(cfg.D)))  # (the launch in front of this readback composited the frame)
+        _live_put(key, live, sampled)  # (the launch in front of this readback composited the frame)
     if guess is None or n > guess[0] or (guess[1] > 0 and max_tile > guess[1]):
         if guess is not None:
             _SIZE_STATS["relaunched"] += 1

@@ -70,7 +70,7 @@ def rasterization(
         "flatten_ids": st.isect["sorted_gid"][: st.n_isect],
         "isect_offsets": st.proj_out["tile_offsets"][:-1].view(1, th, tw),
         "last_ids": st.raster["last_ids"],
-        "n_isect_dev": st.proj_out.get("n_isect"),  # device int64[4]: {count, longest tile list, live rows, -} (include/d4gs.h)
+        "n_isect_dev": st.proj_out.get("n_isect"),  # device int64[4]: {count, longest tile list, sampled entries, sampled live entries} (include/d4gs.h)
         "width": width, "height": height, "tile_size": 16, "tile_width": tw, "tile_height": th, "n_cameras": 1,
         "n_isect": st.n_isect,
     }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D4GS_VERSION 301
+#define D4GS_VERSION 302
 #define D4GS_TILE 16
 #define D4GS_GEOM_STRIDE 8 /* floats per instance record: x, y, opacity, depth, conic a, b, c, pad */
 
@@ -102,11 +102,13 @@ typedef struct D4gsProjOut {
                               d4gs_project_fwd and consumed by d4gs_bin_sort, which therefore runs once per projection
                               (a launch refused by the capacity check does not touch them); T = S*tiles */
   int32_t *tile_offsets;   /* [S*tiles+1] exclusive scan of tile_counts */
-  int64_t *n_isect;        /* [4] {total intersections, longest tile list, live rows, reserved}: [0], [1] are read back by the
-                              host to size the next stage and to pick the sort size classes; [2] (zeroed by d4gs_project_fwd,
-                              accumulated by d4gs_raster_fwd) = the list entries at or in front of their tile's last
-                              contributor, i.e. the rows the backward will replay - [2] / [0] is the live fraction a caller can
-                              choose D4gsRasterGrads.row_mode from (deblur4dgs_amd/engine.py does, one render late) */
+  int64_t *n_isect;        /* [4] {total intersections, longest tile list, sampled entries, sampled live entries}: [0], [1]
+                              are read back by the host to size the next stage and to pick the sort size classes.  [2], [3]
+                              (zeroed by d4gs_project_fwd, accumulated by d4gs_raster_fwd over a fixed sample of <= 128 tiles -
+                              device-scope atomics queue up memory-side, one per tile would cost the composite 5 - 30 %): list
+                              entries of the sampled tiles, and how many of them lie at or in front of their tile's last
+                              contributor, i.e. the rows the backward will replay.  [3] / [2] estimates the live fraction a
+                              caller can choose D4gsRasterGrads.row_mode from (deblur4dgs_amd/engine.py does, one render late) */
   int32_t *scan_ws;        /* [d4gs_scan_ws_elems(S*N)] scratch */
 } D4gsProjOut;
 
@@ -371,7 +373,7 @@ typedef struct D4gsFrameIO {
   float *alphas;           /* [S,H,W] */
   float *means2d;          /* [S,N,2] */
   int32_t *radii;          /* [S,N] */
-  int64_t *n_isect;        /* [4] device: {intersections, longest tile list, live rows, reserved} (D4gsProjOut.n_isect) */
+  int64_t *n_isect;        /* [4] device: {intersections, longest tile list, sampled entries, sampled live entries} (D4gsProjOut.n_isect) */
   const float *background; /* [D] or NULL */
   const int32_t *policy;   /* [host] [D+depth] blend policy per channel (0 mean, 1 max, 2 min) or NULL = all mean */
 } D4gsFrameIO;

@@ -59,7 +59,7 @@ def test_cpu_twin_matches_the_oracle(N, G, K, S, W, H, mask, depth):
     _close("renders", res["renders"], raw_stack)
     _close("blended", res["blended"], blended_ref)
     _close("acc", res["acc"], out["acc"][0, ..., 0])
-    assert int(res["n_isect"][0]) > 0 and 0 < int(res["n_isect"][2]) <= int(res["n_isect"][0])
+    assert int(res["n_isect"][0]) > 0 and 0 < int(res["n_isect"][3]) <= int(res["n_isect"][2]) <= int(res["n_isect"][0])
     ((res["blended"] * w_b.float()).sum() + (res["acc"] * w_a[..., 0].float()).sum() + (res["renders"] * w_r.float()).sum()).backward()
     ref_cat = lambda k: torch.cat([p[k].grad for p in (fg, bg) if p is not None], 0)
     for k in keys:

@@ -70,18 +70,18 @@ def test_deferred_records_queue_up_and_are_all_verified():
             self.done = True
 
     key = ("unit", 1, 2, 3, 4)
-    mk = lambda n, mt, live=0: torch.tensor([n, mt, live, 0], dtype=torch.int64)  # {count, longest list, live rows, -}
-    engine._DEFERRED[key] = [(mk(100, 10, 90), Ev(True), 200, 2048, 1), (mk(900, 10, 900), Ev(True), 200, 2048, 1),
-                             (mk(120, 10, 24), Ev(False), 200, 2048, 2)]
+    mk = lambda n, mt, live=0: torch.tensor([n, mt, 50, live], dtype=torch.int64)  # D4gsProjOut.n_isect: 50 sampled entries
+    engine._DEFERRED[key] = [(mk(100, 10, 45), Ev(True), 200, 2048), (mk(900, 10, 50), Ev(True), 200, 2048),
+                             (mk(120, 10, 10), Ev(False), 200, 2048)]
     with pytest.raises(RuntimeError, match="needed 900 intersections"):
         engine._deferred_poll(key)           # reads the two that have landed; the second one overflowed
     assert len(engine._DEFERRED[key]) == 1   # the pending one is still queued
     assert engine._guess_get(key)[0] >= 900  # the guess follows the largest count seen
-    assert engine._LIVE_FRAC[key] == 0.9     # live fraction of the render that fitted (the overflowed one composited nothing)
+    assert engine._LIVE_FRAC[key] == 45 / 50  # live fraction of the render that fitted (the overflowed one composited nothing)
     assert engine._deferred_poll(key) is None and len(engine._DEFERRED[key]) == 1  # not landed yet, non-blocking
     engine.check_deferred()                  # blocking drain: fits, no error
     assert key not in engine._DEFERRED
-    assert engine._LIVE_FRAC[key] == 24 / (120 * 2)  # two channel chunks composited (and counted) the lists twice
+    assert engine._LIVE_FRAC[key] == 10 / 50
     engine._SIZE_GUESS.pop(key, None)
     engine._LIVE_FRAC.pop(key, None)
 
@@ -95,9 +95,9 @@ def test_row_mode_follows_the_measured_live_fraction(monkeypatch):
     key = engine._size_key(dev, 2, 1000, 64, 48)
     engine._LIVE_FRAC.pop(key, None)
     assert engine.row_mode_for(cfg, dev) == L.ROWS_AUTO
-    engine._live_put(key, 150, 1000, 1)
+    engine._live_put(key, 150, 1000)
     assert engine.row_mode_for(cfg, dev) == L.ROWS_SPARSE
-    engine._live_put(key, 930, 1000, 1)
+    engine._live_put(key, 930, 1000)
     assert engine.row_mode_for(cfg, dev) == L.ROWS_DENSE
     monkeypatch.setattr(engine, "BWD_ROWS", "sparse")
     assert engine.row_mode_for(cfg, dev) == L.ROWS_SPARSE

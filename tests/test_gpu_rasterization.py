@@ -167,11 +167,12 @@ def test_sparse_and_dense_gradient_rows_agree_bitwise(mode, D, monkeypatch):
     for a, b in zip(grads["dense"], grads["sparse"]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
     assert float(grads["dense"][0].abs().max()) > 0
-    # the forward composite counted exactly the rows in front of / at every tile's last contributor (D4gsProjOut.n_isect[2]);
-    # a tile nothing contributed to cannot be told from "entry 0 contributed" through last_ids: one row of slack per tile
-    live = int(info["n_isect_dev"][2])
+    # the forward composite's live-row sample (D4gsProjOut.n_isect[2..3]): on a fixed sample of tiles (every ceil(tiles / 128)-th:
+    # here all of them) the list entries, and those in front of / at the tile's last contributor; a tile nothing contributed
+    # to cannot be told from "entry 0 contributed" through last_ids: one row of slack for tile 0
+    sampled, live = int(info["n_isect_dev"][2]), int(info["n_isect_dev"][3])
     want = int(((tile_last - offs[:-1] + 1).clamp(min=0) * (n_list > 0)).sum())
-    assert abs(live - want) <= int((n_list > 0).sum()) and live < 0.8 * info["n_isect"], (live, want, info["n_isect"])
+    assert sampled == info["n_isect"] and abs(live - want) <= 1 and live < 0.8 * sampled, (sampled, live, want, info["n_isect"])
     # ... and "auto" follows it: the second render of a shape is sized from the first, so its count is the composite's
     from deblur4dgs_amd import _lib as L, engine
 
@@ -181,7 +182,7 @@ def test_sparse_and_dense_gradient_rows_agree_bitwise(mode, D, monkeypatch):
     for _ in range(2):
         _run_gpu(inp, W, H, mode, torch.ones(D), requires_grad=False)
     torch.cuda.synchronize()
-    assert abs(engine._LIVE_FRAC[key] - live / info["n_isect"]) < 1e-6
+    assert abs(engine._LIVE_FRAC[key] - live / sampled) < 1e-6
     cfg = engine.RenderCfg(N=N, G=0, K=0, T=0, S=1, D=D, width=W, height=H)
     assert engine.row_mode_for(cfg, rc.device) == L.ROWS_SPARSE
 
