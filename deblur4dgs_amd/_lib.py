@@ -100,7 +100,7 @@ VERSION = 302  # D4GS_VERSION of include/d4gs.h
 GEOM_STRIDE = 8
 
 EXPORTS = (
-    "d4gs_version", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
+    "d4gs_version", "d4gs_copy_counts", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
     "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_poses_fwd", "d4gs_poses_bwd", "d4gs_forward", "d4gs_backward", "d4gs_forward_cpu", "d4gs_backward_cpu", "d4gs_frame_workspace_bytes", "d4gs_blend_shard_partial_fwd", "d4gs_blend_shard_finish_fwd",
     "d4gs_blend_shard_winner", "d4gs_blend_shard_bwd", "d4gs_control_stats", "d4gs_control_plan", "d4gs_gather_rows", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
         L.d4gs_bwd_partials_elems.argtypes = [C.POINTER(Dims)]
         P = C.POINTER
         vp = C.c_void_p
+        L.d4gs_copy_counts.argtypes = [vp, vp, vp]
         L.d4gs_project_fwd.argtypes = [P(Dims), P(ProjIn), P(ProjOut), vp]
         L.d4gs_bin_sort.argtypes = [P(Dims), P(ProjOut), P(Isect), vp]
         L.d4gs_raster_fwd.argtypes = [P(Dims), P(ProjOut), P(Isect), P(Raster), vp]

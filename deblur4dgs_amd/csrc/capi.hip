@@ -115,6 +115,19 @@ extern "C" {
 
 int d4gs_version(void) { return D4GS_VERSION; }
 
+int d4gs_copy_counts(const int64_t *n_isect, int64_t *host_pinned, void *stream) {
+  if (!n_isect || !host_pinned) {
+    d4gs_set_error("d4gs_copy_counts: NULL argument");
+    return D4GS_EINVAL;
+  }
+  hipError_t e = hipMemcpyAsync(host_pinned, n_isect, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    d4gs_set_error("d4gs_copy_counts: %s", hipGetErrorString(e));
+    return D4GS_ELAUNCH;
+  }
+  return D4GS_OK;
+}
+
 int d4gs_query_sizes(const D4gsDims *d, D4gsSizes *z) {
   int rc = check_dims(d);
   if (rc) return rc;

@@ -240,6 +240,67 @@ def _deferred_poll(key, block: bool = False):
     return last
 
 
+_GRAPH_WATCH = None  # the GraphWatch whose capture is in progress (set by GraphWatch.capturing())
+
+
+class GraphWatch:
+    """Size checks for a step replayed from a HIP graph.  A captured render keeps the list capacities of its capture, and its
+    kernels skip their work when the device-side count exceeds them - nobody would notice: the loss would be computed on
+    stale images and the optimizer would step on zero raster gradients.  Capture inside `with watch.capturing():` and every
+    deferred render of the step leaves a device-to-pinned copy of its counts IN the graph; `watch.replayed()` after each
+    `graph.replay()` and `watch.check()` before the next one (no stall in the steady state: the previous replay has long
+    finished) raises RuntimeError - and updates the size guesses - if a render of the previous replay overflowed, so the
+    caller re-captures (after an eager step or two, which size the lists from the new counts)."""
+
+    def __init__(self, max_renders: int = 32):
+        self.recs = []  # (size key, pinned int64[4], capacity, max-tile hint) per captured render
+        self.event = None
+        self._pool = [torch.zeros(4, dtype=torch.int64).pin_memory() for _ in range(max_renders)]  # pinned before the capture
+
+    def take(self):
+        if not self._pool:
+            raise RuntimeError("GraphWatch: more renders in the captured step than max_renders")
+        return self._pool.pop()
+
+    def capturing(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            global _GRAPH_WATCH
+            assert _GRAPH_WATCH is None, "nested GraphWatch captures"
+            _GRAPH_WATCH = self
+            try:
+                yield self
+            finally:
+                _GRAPH_WATCH = None
+
+        return cm()
+
+    def replayed(self):
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def check(self):
+        if self.event is None:
+            return
+        self.event.synchronize()
+        self.event = None
+        bad = None
+        for key, host_n, cap, hint in self.recs:
+            n, max_tile, sampled, live = host_n.tolist()
+            if n > cap or (hint > 0 and max_tile > hint):
+                _guess_put(key, (n + n // 4 + 4096, _sort_class(max_tile)))
+                bad = bad or (n, max_tile, cap, hint)
+            else:
+                _live_put(key, live, sampled)
+        if bad is not None:
+            n, max_tile, cap, hint = bad
+            raise RuntimeError(f"deblur4dgs_amd: a render replayed from a HIP graph needed {n} intersections (longest tile list "
+                               f"{max_tile}) but the graph was captured with lists for {cap} (class {hint}): that replay's output "
+                               "was INVALID (its kernels skipped the work).  Re-capture the step; the size guess is updated.")
+
+
 def check_deferred():
     """Wait for and verify every outstanding deferred size check (call once per training step, e.g. where the loss is
     read back anyway).  Raises RuntimeError if any render since the last call overflowed its intersection lists."""
@@ -401,6 +462,13 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
             # deferred check: launch at the guessed capacity, never wait.  The count travels to pinned memory behind
             # the launches and is looked at by a later call (not under stream capture: a graph replays this shape).
             launch(*guess)
+            if capturing and _GRAPH_WATCH is not None:
+                # the copy of the counts becomes a node of the graph: every replay leaves them in this record's pinned buffer
+                # (a raw hipMemcpyAsync into memory pinned BEFORE the capture: neither an allocation nor torch's host-allocator
+                # bookkeeping may happen on a capturing stream)
+                host_n = _GRAPH_WATCH.take()
+                L.check(L.lib().d4gs_copy_counts(L.ptr(n_isect_dev()), host_n.data_ptr(), raw_stream(dev.index)), "copy_counts")
+                _GRAPH_WATCH.recs.append((key, host_n, guess[0], guess[1]))
             if not capturing:
                 with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
                     host_n = _PINNED_FREE.pop() if _PINNED_FREE else None

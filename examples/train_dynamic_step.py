@@ -86,25 +86,32 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, f
         return loss.detach(), side
 
     params = [p for o in opts() for g in o.param_groups for p in g["params"]]
-    captured = None  # (graph, static loss)
+    captured = None  # (graph, static loss, engine.GraphWatch)
     eager_since_capture = 0
     for it in range(steps):
         if it == warm:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        if graph and captured is not None and it % 25 == 0:
-            # a replayed graph keeps the list capacities of its capture and nobody looks at the device-side counts: go
-            # back to two eager (deferred-checked) steps now and then, so the capacities follow the scene as it trains
-            captured, eager_since_capture = None, 0
+        if captured is not None:
+            # a replayed graph keeps the list capacities of its capture: the counts of the PREVIOUS replay (copied to pinned
+            # memory by nodes of the graph itself) are looked at before the next one - an overflowed replay rendered nothing,
+            # so its step is void; go back to eager steps, which size the lists from the new counts, and capture again
+            try:
+                captured[2].check()
+            except RuntimeError as e:
+                if verbose:
+                    print(f"step {it:3d}  {e}")
+                captured, eager_since_capture = None, 0
         if graph and captured is None and eager_since_capture >= 2:
             for p_ in params:
                 p_.grad = None
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_):
+            g_, watch = torch.cuda.CUDAGraph(), engine.GraphWatch()
+            with watch.capturing(), torch.cuda.graph(g_):
                 loss_static, _ = fwd_bwd()
-            captured = (g_, loss_static)
+            captured = (g_, loss_static, watch)
         if captured is not None:
             captured[0].replay()  # gradients land in the same .grad tensors every step
+            captured[2].replayed()
             loss, side = captured[1], None
         else:
             for o in opts():

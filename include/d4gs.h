@@ -183,6 +183,9 @@ int d4gs_version(void);
 void d4gs_profile_enable(int on);
 int d4gs_profile_collect(char *buf /* [host] */, size_t cap);
 const char *d4gs_last_error(void);
+/* D4gsProjOut.n_isect -> pinned host memory, as ONE asynchronous copy on `stream` (hipMemcpyAsync; a memcpy node when the stream
+ * is being captured - how a step replayed from a HIP graph keeps reporting its list sizes: engine.GraphWatch). */
+int d4gs_copy_counts(const int64_t *n_isect /* device [4] */, int64_t *host_pinned /* [4] */, void *stream);
 size_t d4gs_scan_ws_elems(int64_t n_instances);
 size_t d4gs_bwd_partials_elems(const D4gsDims *dims);
 

@@ -125,3 +125,47 @@ def test_whole_render_forward_and_backward_replays_from_a_hip_graph():
         assert torch.equal(r_g["blended"], r_e["blended"]), it
         for k in NAMES:
             assert torch.equal(static[k].grad, eager[k].grad), (it, k)
+
+
+def test_a_replayed_graph_reports_lists_that_outgrew_their_capture():
+    """a captured step keeps the list capacities of its capture and its kernels skip their work when the device-side
+    count exceeds them.  engine.GraphWatch puts the copy of the counts INTO the graph; check() before the next replay raises
+    when the scene has outgrown the capture (and updates the size guess), and stays silent while it fits."""
+    from deblur4dgs_amd import engine
+
+    dev = torch.device("cuda:0")
+    N, G, K_, S, W, H = 6000, 3000, 3, 2, 128, 96
+    sc = make_scene(N, G, K_, S, W, H, seed=21)
+    K = sc["K"].to(dev)
+    w = torch.randn(H, W, 4, generator=torch.Generator().manual_seed(2)).to(dev)
+    static = _leaves(sc, dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for v in static.values():
+                v.grad = None
+            _step(static, K, W, H, w, deferred_size_check=True)
+    torch.cuda.current_stream().wait_stream(side)
+    engine.check_deferred()
+    for v in static.values():
+        v.grad = None
+    graph, watch = torch.cuda.CUDAGraph(), engine.GraphWatch()
+    with watch.capturing(), torch.cuda.graph(graph):
+        _step(static, K, W, H, w, deferred_size_check=True)
+    assert len(watch.recs) == 1
+    graph.replay()
+    watch.replayed()
+    watch.check()  # fits: silent
+    n0 = int(watch.recs[0][1][0])
+    assert 0 < n0 <= watch.recs[0][2]
+    with torch.no_grad():  # the scene grows under the captured graph: 12x larger splats -> far more intersections
+        static["scales"].add_(2.5)
+    graph.replay()
+    watch.replayed()
+    torch.cuda.synchronize()
+    assert int(watch.recs[0][1][0]) > watch.recs[0][2], (n0, watch.recs[0][1].tolist(), watch.recs[0][2])
+    with pytest.raises(RuntimeError, match="replayed from a HIP graph needed"):
+        watch.check()
+    key = watch.recs[0][0]
+    assert engine._guess_get(key)[0] > watch.recs[0][2]  # the next eager / captured step is sized for the new count
