@@ -220,7 +220,14 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
                              : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
         const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
 #pragma unroll
-        for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
+        for (int v = 0; v < DV; v++) {
+          float4 c4 = cp[v];
+          // the depth rides in the colour record's padding slot (D = 3: r, g, b, depth): one LDS read per replay instead of two
+          if constexpr (DEPTH && (D & 3) != 0) {
+            if (v == D / 4) (&c4.x)[D & 3] = q0.w;
+          }
+          scol[tid * DV + v] = c4;
+        }
       }
     }
     for (int z = tid; z < 4 * NB * RP; z += 256) sgrad[z] = 0.f;
@@ -255,12 +262,13 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
 #pragma unroll
         for (int v = 0; v < DV; v++) {
           const float4 c4 = scol[j * DV + v];
-          if (v * 4 < D) d = __builtin_fmaf(vo[v * 4], c4.x, d);
-          if (v * 4 + 1 < D) d = __builtin_fmaf(vo[v * 4 + 1], c4.y, d);
-          if (v * 4 + 2 < D) d = __builtin_fmaf(vo[v * 4 + 2], c4.z, d);
-          if (v * 4 + 3 < D) d = __builtin_fmaf(vo[v * 4 + 3], c4.w, d);
+          constexpr int DC = D + ((DEPTH && (D & 3) != 0) ? 1 : 0);  // channels the record holds (vo[D] = the depth channel)
+          if (v * 4 < DC) d = __builtin_fmaf(vo[v * 4], c4.x, d);
+          if (v * 4 + 1 < DC) d = __builtin_fmaf(vo[v * 4 + 1], c4.y, d);
+          if (v * 4 + 2 < DC) d = __builtin_fmaf(vo[v * 4 + 2], c4.z, d);
+          if (v * 4 + 3 < DC) d = __builtin_fmaf(vo[v * 4 + 3], c4.w, d);
         }
-        if (DEPTH) d = __builtin_fmaf(vo[D], g0.w, d);
+        if (DEPTH && (D & 3) == 0) d = __builtin_fmaf(vo[D], g0.w, d);
 #pragma unroll
         for (int c = MC; c < NCH; c++) row[6 + c - MC] = fac * vo[c];
         if constexpr (MC > 0) {
