@@ -453,6 +453,14 @@ def main():
                 graph_note["fallback"] = f"graph capture failed ({type(e).__name__}: {e}); timed the eager step"
                 sys.stderr.write(graph_note["fallback"] + "\n")
                 torch.cuda.synchronize()
+            if use_dist:  # every rank must take the same path: one that could not capture sends them all to the eager step
+                import torch.distributed as dist
+
+                ok = torch.tensor([1 if captured else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if captured and int(ok.item()) == 0:
+                    captured = False
+                    graph_note["fallback"] = "another rank could not capture its step; timed the eager step"
             if captured:
                 def step():  # noqa: F811
                     graph.replay()
