@@ -196,7 +196,7 @@ def row_mode_for(cfg, dev):
     return L.ROWS_SPARSE if f < LIVE_SPARSE_BELOW else L.ROWS_DENSE
 
 
-_DEFERRED: dict = {}  # size key -> [(pinned int64[2], event, capacity, max-tile hint), ...]: EVERY unchecked render of that
+_DEFERRED: dict = {}  # size key -> [(pinned int64[4], event, capacity, max-tile hint), ...]: EVERY unchecked render of that
 #                       shape, oldest first (a training step issues several renders of one shape before any count lands)
 
 
@@ -315,7 +315,7 @@ def check_deferred():
 
 
 def _pinned_counts(dev):
-    """One pinned int64[2] per (thread, device, stream): every use is followed by an event wait before the next one on
+    """One pinned int64[4] per (thread, device, stream): every use is followed by an event wait before the next one on
     that stream, and two streams of one thread never share a buffer."""
     k = (threading.get_ident(), dev.index, raw_stream(dev.index))
     with _SIZE_LOCK:
@@ -449,7 +449,7 @@ def _check_stats(cs: dict, N: int) -> dict:
 def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch: bool = False):
     """The intersection-list size protocol shared by the staged and the one-call path.  `launch(capacity, max_tile_hint)`
     allocates the lists and enqueues binning + rasterization (every kernel checks the device-side count against the
-    capacity); `n_isect_dev()` is the device int64[2] {count, longest tile list} of the launch just made (staged path:
+    capacity); `n_isect_dev()` is the device int64[4] {count, longest tile list, live-row sample x 2} of the launch just made (staged path:
     already there, the projection ran before; one-call path, `count_needs_launch`: a capacity-0 call whose list kernels
     all return at once does the counting).  -> (capacity or exact count, max-tile value) the backward must use."""
     key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
