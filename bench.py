@@ -273,7 +273,7 @@ def cpu_baseline(name, channels, full=False):
                       f"oracle/raster_ref.c (scalar C, fp32) with the {S} sub-samples on {head['cores']} parallel threads + torch "
                       f"deformation; median {head['s_per_frame_median']:.2f} s per frame (min {head['s_per_frame_min']:.2f}, max "
                       f"{head['s_per_frame_max']:.2f}); `runs` holds cfg1 in full (20 iterations); the torch restatement's leg "
-                      f"of BASELINE.md section 3 runs with --cpu-baseline-full (profiles/r02_cpu_baseline_full.json)")
+                      f"of BASELINE.md section 3 runs with --cpu-baseline-full (profiles/r03_cpu_baseline_full.json)")
     return out
 
 
