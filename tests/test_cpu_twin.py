@@ -112,3 +112,29 @@ def test_cpu_twin_is_an_entry_point_not_a_fallback():
                                  sc["RTs"], sc["viewmat"], sc["K"], 32, 32)
     src = open(exposure.__file__).read() + open(exposure.__file__.replace("exposure.py", "engine.py")).read()
     assert "cpu_twin" not in src and "_cpu(" not in src  # nothing on the device path routes here
+
+
+def test_cpu_twin_activated_inputs_no_background_no_blend():
+    """The gsplat-seam flavour of the flags: activated scales / opacities (raw_params=False), no background, blend off."""
+    from deblur4dgs_amd.cpu_twin import render_exposure_cpu
+    from oracle import raster
+    from tests.util import static_inputs
+
+    W, H, N = 72, 56, 500
+    inp = static_inputs(N, W, H, seed=77, dtype=torch.float64, D=3, scale_mul=3.0)
+    ref = {k: v.clone().requires_grad_() for k, v in inp.items() if k in ("means", "quats", "scales", "opac", "colors")}
+    rc, ra, _ = raster.rasterization(ref["means"], ref["quats"], ref["scales"], ref["opac"], ref["colors"], inp["V"], inp["K"], W, H,
+                                     background=None, render_mode="RGB")
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(rc.shape, generator=g, dtype=torch.float64)
+    ((rc * w).sum() + 0.3 * ra.sum()).backward()
+    P = {k: inp[k].float().requires_grad_() for k in ref}
+    res = render_exposure_cpu(P["means"], P["quats"], P["scales"], P["opac"], P["colors"], 0, None, None, None, None, None,
+                              inp["V"].float(), inp["K"].float(), W, H, background=None, return_depth=False, blend=False,
+                              raw_params=False)
+    assert res["blended"] is None and res["renders"].shape == (1, H, W, 3)
+    _close("renders", res["renders"][0], rc)
+    _close("alphas", res["alphas"][0, ..., 0], ra[..., 0])
+    ((res["renders"][0] * w.float()).sum() + 0.3 * res["alphas"].sum()).backward()
+    for k in ref:
+        _close(k, P[k].grad, ref[k].grad)
