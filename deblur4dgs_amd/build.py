@@ -25,6 +25,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 FILE_FLAGS = {"project_bwd.hip": ["-fno-slp-vectorize"]}
 
 
+def _cuid(src: str) -> str:
+    """hipcc derives a compilation-unit id from the ABSOLUTE source path; a fixed one makes libd4gs.so byte-identical wherever the
+    tree is checked out (profiles/pmc_current.json pins the counter files to the library's sha256)."""
+    return "-cuid=d4gs_" + os.path.splitext(src)[0]
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -41,7 +47,7 @@ def _stale(src: str, obj: str) -> bool:
 def _compile(src: str, extra: list[str], suffix: str = ".o") -> str:
     obj = os.path.join(OBJ, src.replace(".hip", suffix))
     if _stale(src, obj) or (extra and suffix == ".o"):
-        cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(src, []), _cuid(src), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -88,7 +94,7 @@ def build_ab(name: str, src: str, defines: list[str]) -> str:
     out_dir = os.path.join(HERE, "..", "scripts", "ablate")
     os.makedirs(out_dir, exist_ok=True)
     obj = os.path.join(out_dir, f"ab_{name}.o")
-    cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(src, []), *defines, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(src, []), _cuid(src), *defines, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
