@@ -377,6 +377,31 @@ def main():
 
     graph_note = {}
 
+    def measured_peaks():
+        """SURVEY 8d / BASELINE.md section 4: the ceilings are MEASURED on this box, before the timed region - a ~1 GiB
+        device-to-device stream copy and an FMA issue loop (d4gs_measure_peaks, csrc/peaks.hip; ~30 ms of device time)."""
+        try:
+            scratch = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            scratch.zero_()
+            out = (C.c_double * 4)()
+            rc = lib.d4gs_measure_peaks(C.c_void_p(scratch.data_ptr()), C.c_size_t(scratch.numel()), out,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            del scratch
+            torch.cuda.empty_cache()
+            if rc != 0:
+                return None
+            return {"hbm_stream_copy_gbs": out[0], "fp32_pk_fma_tflops": out[1], "fp32_fma_tflops": out[2],
+                    "copy_bytes_per_launch": out[3],
+                    "how": "d4gs_measure_peaks on this GPU right before the timed region: device-to-device float4 stream copy "
+                           "(read + write bytes / best of 8 launches), v_pk_fma_f32 and v_fma_f32 issue loops at 8 waves per SIMD "
+                           "(16 independent chains per lane, best of 5)"}
+        except Exception as e:  # the ceilings are context, not the measurement: never take the bench line down
+            sys.stderr.write(f"d4gs_measure_peaks failed: {e!r}\n")
+            return None
+
+    peaks = measured_peaks() if rank == 0 else None
+
     def measure(mode, steps, warmup, profile):
         """-> (seconds for `steps` steps: max over ranks, live kernel timings, last state)"""
         views = use_dist and mode == "views"
@@ -537,6 +562,7 @@ def main():
         n_isect = st.n_isect
         S_loc = st.cfg.S
         out["n_isect_per_step"] = n_isect if world == 1 else None
+        out["peaks_measured"] = peaks
         if kern:
             per = {k: v[1] / n_break for k, v in sorted(kern_all.items(), key=lambda kv: -kv[1][1])}
             out["kernels_ms_per_step"] = per
@@ -566,7 +592,11 @@ def main():
                 roof = {"kernel": dom, "bound": "mfma", "bound_actual": "fp32 VALU issue (no MFMA is issued; the contract's "
                         "field only admits hbm|mfma and 157.3 TFLOP/s is both the fp32 vector and the fp32-input MFMA peak)",
                         "achieved": flops / t_k / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS, "traffic": tr["total_1x"] if tr else None,
+                        "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS,
+                        "peak_measured": peaks["fp32_pk_fma_tflops"] if peaks else None,
+                        "frac_of_measured": (flops / t_k / 1e12 / peaks["fp32_pk_fma_tflops"]) if peaks else None,
+                        "peak_measured_plain_fma": peaks["fp32_fma_tflops"] if peaks else None,
+                        "traffic": tr["total_1x"] if tr else None,
                         "traffic_detail": tr, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
                         "note": "NOMINAL work-equivalent fraction (SURVEY 8d): 90 flop x 256 pixels for every (tile, splat) "
                                 "pair the kernel replays, although the kernel skips most of those pixels by design; the "
@@ -605,6 +635,8 @@ def main():
                 out["roofline"] = roof
                 out["roofline_hbm"] = {"kernel": dom, "bound": "hbm", "achieved": bytes_bwd / t_k / 1e9,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_bwd / t_k / 1e9 / HBM_PEAK_GBS,
+                                       "peak_measured": peaks["hbm_stream_copy_gbs"] if peaks else None,
+                                       "frac_of_measured": (bytes_bwd / t_k / 1e9 / peaks["hbm_stream_copy_gbs"]) if peaks else None,
                                        "traffic": tr["total_1x"] if tr else None, "algorithmic_bytes": bytes_bwd}
             else:
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
@@ -627,6 +659,8 @@ def main():
                     tr = _traffic(name, kname) if channels == 3 and args.scale_mul == 1.0 else None
                     stream.append({"kernel": kname, "bound": "hbm", "algorithmic_bytes": b, "avg_launch_ms": per[kname],
                                    "achieved": b / tk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / tk / 1e9 / HBM_PEAK_GBS,
+                                   "peak_measured": peaks["hbm_stream_copy_gbs"] if peaks else None,
+                                   "frac_of_measured": (b / tk / 1e9 / peaks["hbm_stream_copy_gbs"]) if peaks else None,
                                    "traffic": tr["total_2x"] if tr else None, "traffic_detail": tr,
                                    "traffic_frac_of_peak": (tr["total_2x"] / tk / 1e9 / HBM_PEAK_GBS) if tr else None})
             out["roofline_streaming"] = stream

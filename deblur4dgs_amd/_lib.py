@@ -96,7 +96,7 @@ RAW_PARAMS, RAW_COLORS, EXACT_CULL = 1, 2, 4
 DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
 ROWS_AUTO, ROWS_DENSE, ROWS_SPARSE = 0, 1, 2
 TILE = 16
-VERSION = 302  # D4GS_VERSION of include/d4gs.h
+VERSION = 303  # D4GS_VERSION of include/d4gs.h
 GEOM_STRIDE = 8
 
 EXPORTS = (
@@ -105,7 +105,7 @@ EXPORTS = (
     "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_poses_fwd", "d4gs_poses_bwd", "d4gs_forward", "d4gs_backward", "d4gs_forward_cpu", "d4gs_backward_cpu", "d4gs_frame_workspace_bytes", "d4gs_blend_shard_partial_fwd", "d4gs_blend_shard_finish_fwd",
     "d4gs_blend_shard_winner", "d4gs_blend_shard_bwd", "d4gs_control_stats", "d4gs_control_plan", "d4gs_gather_rows", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
     "d4gs_pose_encode", "d4gs_pose_encode_bwd", "d4gs_move_model_fwd", "d4gs_move_model_bwd",
-    "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_query_sizes", "d4gs_profile_enable", "d4gs_profile_collect",
+    "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_query_sizes", "d4gs_profile_enable", "d4gs_profile_collect", "d4gs_measure_peaks",
 )
 
 _lib = None
@@ -131,6 +131,7 @@ def lib() -> C.CDLL:
         P = C.POINTER
         vp = C.c_void_p
         L.d4gs_copy_counts.argtypes = [vp, vp, vp]
+        L.d4gs_measure_peaks.argtypes = [vp, C.c_size_t, P(C.c_double), vp]
         L.d4gs_project_fwd.argtypes = [P(Dims), P(ProjIn), P(ProjOut), vp]
         L.d4gs_bin_sort.argtypes = [P(Dims), P(ProjOut), P(Isect), vp]
         L.d4gs_raster_fwd.argtypes = [P(Dims), P(ProjOut), P(Isect), P(Raster), vp]

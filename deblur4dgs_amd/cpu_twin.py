@@ -96,6 +96,10 @@ def render_exposure_cpu(means, quats, scales, opacities, colors, n_sigmoid, moti
     dims = L.Dims(N=N, G=G, K=0 if G == 0 else rots.shape[0], T=0 if G == 0 else rots.shape[1], S=S, D=colors.shape[-1],
                   width=width, height=height, depth_mode=L.DEPTH_ED if return_depth else L.DEPTH_NONE, flags=flags,
                   n_sigmoid=n_sigmoid, near_plane=0.01, far_plane=1e10, eps2d=0.3, radius_clip=0.0)
+    if blend and policy is None:  # the device path's default: channel 3 <- max_S, channel 16 <- min_S (scene_model.py:392-393)
+        from .exposure import reference_policy
+
+        policy = reference_policy(dims.D + (1 if return_depth else 0))
     out = FrameCpuFn.apply((dims, policy, blend), means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs,
                            w2c, Kmat, background)
     return dict(zip(("blended", "acc", "renders", "alphas", "means2d", "radii", "n_isect"), out))

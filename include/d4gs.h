@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D4GS_VERSION 302
+#define D4GS_VERSION 303
 #define D4GS_TILE 16
 #define D4GS_GEOM_STRIDE 8 /* floats per instance record: x, y, opacity, depth, conic a, b, c, pad */
 
@@ -183,6 +183,11 @@ int d4gs_version(void);
 void d4gs_profile_enable(int on);
 int d4gs_profile_collect(char *buf /* [host] */, size_t cap);
 const char *d4gs_last_error(void);
+/* The two MEASURED device ceilings bench.py quotes its roofline fractions against: a device-to-device stream copy over
+ * `scratch` (first half -> second half, best of 8) and an FMA issue loop at 8 waves per SIMD.  out[0] = copy GB/s (read + write),
+ * out[1] = fp32 TFLOP/s with v_pk_fma_f32, out[2] = fp32 TFLOP/s with v_fma_f32 (what the composite kernels issue), out[3] = bytes
+ * copied per launch.  Diagnostic: creates its own HIP events and WAITS for them - not for timed regions or stream captures. */
+int d4gs_measure_peaks(void *scratch /* device, >= 64 MiB */, size_t scratch_bytes, double *out /* [host] [4] */, void *stream);
 /* D4gsProjOut.n_isect -> pinned host memory, as ONE asynchronous copy on `stream` (hipMemcpyAsync; a memcpy node when the stream
  * is being captured - how a step replayed from a HIP graph keeps reporting its list sizes: engine.GraphWatch). */
 int d4gs_copy_counts(const int64_t *n_isect /* device [4] */, int64_t *host_pinned /* [4] */, void *stream);

@@ -138,3 +138,25 @@ def test_cpu_twin_activated_inputs_no_background_no_blend():
     ((res["renders"][0] * w.float()).sum() + 0.3 * res["alphas"].sum()).backward()
     for k in ref:
         _close(k, P[k].grad, ref[k].grad)
+
+
+def test_cpu_twin_default_policy_is_the_reference_policy():
+    """`policy=None` must mean what it means on the device path - channel 3 <- max_S, channel 16 <- min_S
+    (scene_model.py:392-393) - not "mean everywhere".  S > 1 and NCH > 3 (RGB + depth), default arguments."""
+    from deblur4dgs_amd.cpu_twin import render_exposure_cpu
+    from deblur4dgs_amd.exposure import reference_policy
+
+    N, G, K, S, W, H = 300, 200, 3, 3, 48, 40
+    sc = make_scene(N, G, K, S, W, H, seed=911, dtype=torch.float32, cam_jitter=0.01)
+    sc["scales"] = sc["scales"] + 1.2
+    args = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["colors"], 3, sc["motion_coefs"], sc["rots"], sc["transls"],
+            sc["times"], sc["RTs"], sc["viewmat"], sc["K"], W, H)
+    dflt = render_exposure_cpu(*args, background=torch.ones(3), return_depth=True)
+    expl = render_exposure_cpu(*args, background=torch.ones(3), return_depth=True, policy=reference_policy(4))
+    mean = render_exposure_cpu(*args, background=torch.ones(3), return_depth=True, policy=[0, 0, 0, 0])
+    assert torch.equal(dflt["blended"], expl["blended"])
+    assert torch.equal(dflt["blended"][..., :3], mean["blended"][..., :3])
+    assert not torch.equal(dflt["blended"][..., 3], mean["blended"][..., 3])  # the depth channel takes the max, not the mean
+    raw = dflt["renders"][..., 3]
+    want = torch.maximum(raw[:-1].amax(0), raw.mean(0))  # max{raw_0 .. raw_{S-2}, mean}: the reference's in-place quirk
+    assert torch.allclose(dflt["blended"][..., 3], want, rtol=1e-6, atol=1e-6)
