@@ -8,12 +8,13 @@
 namespace {
 
 // device-to-device stream copy, 16 bytes per lane and access, grid-stride over a grid that fills the machine
-__global__ void __launch_bounds__(256) k_peak_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_peak_copy(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t n4) {
   const size_t stride = (size_t)gridDim.x * 256;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
-    const float4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-    const float4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    const v4f a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const v4f c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
     __builtin_nontemporal_store(a, dst + i), __builtin_nontemporal_store(b, dst + i + stride);
     __builtin_nontemporal_store(c, dst + i + 2 * stride), __builtin_nontemporal_store(d, dst + i + 3 * stride);
   }
@@ -84,8 +85,8 @@ extern "C" int d4gs_measure_peaks(void *scratch, size_t scratch_bytes, double *o
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   // ---- stream copy: first half -> second half, best of 8 after 2 warm-ups
   const size_t half = (scratch_bytes / 2) & ~(size_t)4095, n4 = half / 16;
-  const float4 *src = reinterpret_cast<const float4 *>(scratch);
-  float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<char *>(scratch) + half);
+  const v4f *src = reinterpret_cast<const v4f *>(scratch);
+  v4f *dst = reinterpret_cast<v4f *>(reinterpret_cast<char *>(scratch) + half);
   float best_copy = 1e30f;
   for (int rep = 0; rep < 10; rep++) {
     (void)hipEventRecord(t.a, stream);
