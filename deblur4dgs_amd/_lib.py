@@ -38,7 +38,7 @@ class Isect(C.Structure):
 
 
 class Raster(C.Structure):
-    _fields_ = [(n, F) for n in ("background", "render_colors", "render_alphas", "last_ids", "final_T")]
+    _fields_ = [(n, F) for n in ("background", "render_colors", "render_alphas", "last_ids", "final_T", "seg_state")]
 
 
 class RasterGrads(C.Structure):
@@ -51,7 +51,7 @@ class Sizes(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects",
                                          "tiles_touched", "isect_offsets", "tile_counts", "tile_offsets", "n_isect",
                                          "scan_ws", "render_colors", "render_alphas", "last_ids", "final_T",
-                                         "isect_grad_row", "bwd_partials")] + \
+                                         "isect_grad_row", "bwd_partials", "seg_state")] + \
                [(n, C.c_int32) for n in ("tiles_x", "tiles_y", "channels")]
 
 

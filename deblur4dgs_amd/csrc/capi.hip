@@ -145,6 +145,7 @@ int d4gs_query_sizes(const D4gsDims *d, D4gsSizes *z) {
   z->render_colors = S * H * W * nch, z->render_alphas = S * H * W, z->last_ids = S * H * W, z->final_T = S * H * W;
   z->isect_grad_row = 6 + nch;
   z->bwd_partials = (int64_t)d4gs_bwd_partials_elems(d);
+  z->seg_state = d4gs_seg_state_elems(d);
   z->tiles_x = (int32_t)tw, z->tiles_y = (int32_t)th, z->channels = (int32_t)nch;
   return D4GS_OK;
 }

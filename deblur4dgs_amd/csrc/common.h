@@ -301,6 +301,25 @@ __device__ __forceinline__ void project_instance(const Cam &cam, const float *mw
   o.radius = (int)radius;
 }
 
+// ---- depth segments of the tile lists (round 4) ---------------------------------------------------------------------
+// A rank of an exposure-sharded frame composites S / P sub-samples: at S = 1 and 288x512 that is 576 tiles = 2 304 waves for 8 192
+// wave slots, and the composite kernels' time goes with 1 / occupancy.  The BACKWARD therefore splits every tile list into up to
+// D4GS_SEG_MAX depth segments that separate workgroups replay in parallel: the forward leaves, per pixel, the transmittance and
+// the accumulated channels at every segment boundary (+ the final ones), from which a segment's workgroup starts exactly where
+// the sequential replay would be (T at the boundary; the suffix dot product <v_out, C_final - C_boundary>).
+// Segment length of a list of `len` entries: a multiple of 256 (= the forward's batch or twice it), at most D4GS_SEG_MAX segments.
+#define D4GS_SEG_MAX 8
+#define D4GS_SEG_UNIT 256
+#define D4GS_SEG_TILES_MAX 1280  // S * tiles above this: the plain kernels already fill the machine (>= 5 waves per SIMD)
+__host__ __device__ __forceinline__ int d4gs_seg_len(int len) {
+  const int per = (len + D4GS_SEG_UNIT * D4GS_SEG_MAX - 1) / (D4GS_SEG_UNIT * D4GS_SEG_MAX);
+  return D4GS_SEG_UNIT * (per > 1 ? per : 1);
+}
+// floats of D4gsRaster.seg_state for one configuration (0: segments are not used for it)
+int64_t d4gs_seg_state_elems(const D4gsDims *d);
+// do the composite kernels of this launch use segments?  (the forward writes the boundary states, the backward replays by segment)
+bool d4gs_seg_on(const D4gsDims *d, const D4gsIsect *isect, const D4gsRaster *r);
+
 // > 0: the fused scan is in effect for this configuration and this is its chunk count per sub-sample (project_fwd.hip)
 int d4gs_fused_scan_chunks(const D4gsDims *d);
 

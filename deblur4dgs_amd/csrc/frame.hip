@@ -55,6 +55,7 @@ FrameBufs carve(const D4gsDims *d, int64_t cap, void *ws) {
   b.isect.keys = c.take<uint64_t>(m), b.isect.gid_of_emit = c.take<int32_t>(m);
   b.isect.sorted_gid = c.take<int32_t>(m), b.isect.sorted_emit = c.take<int32_t>(m);
   b.raster.last_ids = c.take<int32_t>(z.last_ids), b.raster.final_T = c.take<float>(z.final_T);
+  b.raster.seg_state = z.seg_state > 0 ? c.take<float>(z.seg_state) : nullptr;  // few-tile launches: depth-segment boundary states
   // backward scratch
   b.v_renders = c.take<float>(z.render_colors), b.v_alphas = c.take<float>(z.render_alphas);
   b.isect_grad = c.take<float>(m * (size_t)z.isect_grad_row), b.isect_live = c.take<uint8_t>((m + 3) & ~(size_t)3);

@@ -12,6 +12,10 @@
 //     block partial directly - no cross-wave sum, no block barrier inside the sub-sample loop;
 //   * per-Gaussian leaf gradients are accumulated over a slot's sub-samples in registers (fixed order), the 4 slots are
 //     then added through LDS in fixed order ((0+1)+(2+3)) and written once - no atomics, bit-reproducible.
+// Small S (round 4; a rank of an exposure-sharded frame renders S / P sub-samples): with fewer than 4 sub-samples the slots
+// beyond S would idle (S = 1: three of the four waves).  The block then owns 64 * NSG Gaussians, NSG = 4 / SL SUB-GROUPS of SL
+// slots each (SL = 1 for S = 1, 2 for S = 2, 4 otherwise): wave w is slot w % SL of sub-group w / SL, everything above holds per
+// sub-group, and a sub-group leaves its own shared-gradient partial vector.  S >= 3 is the round-3 mapping, bit for bit.
 // (Round 2: one lane per Gaussian looping over S with 27 accumulators at 253 VGPRs, 2 waves / SIMD, 4 688 waves for
 // 2 048 wave slots on cfg2.)  Block partials of the shared gradients are summed over blocks by k_reduce_partials in a
 // fixed order and scattered to rots / transls / times by k_finish.
@@ -44,6 +48,9 @@ struct BwdArgs {
   int g_major;                // 1: the Gaussian-major layouts (the reference's (G,B,...) tensors)
   int persist;                // 1: a fixed grid of blocks walks the 64-Gaussian groups and keeps its shared-gradient sums in LDS
 };
+// slots per sub-group for S sub-samples (the poses adjoint keeps the 4-slot mapping: it is not on the per-frame path)
+template <int MODE>
+int slots_of(int S) { return (MODE != MODE_RENDER || S >= 3) ? 4 : S == 2 ? 2 : 1; }
 
 #ifndef PB_MFMA_WAVES
 #define PB_MFMA_WAVES 3
@@ -71,7 +78,7 @@ __device__ __forceinline__ void rotmat_adj_to_quat(const float *q, const float *
   v_q[3] += 2.f * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
 }
 
-template <int MODE, bool MFMA /* K > 8: basis-gradient column sums on the matrix pipe */>
+template <int MODE, bool MFMA /* K > 8: basis-gradient column sums on the matrix pipe */, int SL /* slots per sub-group */>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ? PB_MFMA_WAVES : 4))) k_project_bwd(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const D4gsDims &d = a.d;
@@ -82,8 +89,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   const int nk = K * 9, nk4 = (nk + 3) & ~3, nop = nk + 13;
   const bool shared = dyn || a.in.RTs;
   const int no = nk + 12;
-  float *cf = smem;                   // [GPB][KP]    softmaxed coefficients of the block's Gaussians
-  float *vcf = cf + GPB * KP;         // [BLK][KP]    their gradients, per slot, summed over the slot's sub-samples
+  constexpr int NSG = SLOTS / SL;  // sub-groups per block (SL = 4: one, the round-3 mapping)
+  float *cf = smem;                   // [NSG][GPB][KP] softmaxed coefficients of the block's Gaussians
+  float *vcf = cf + NSG * GPB * KP;   // [BLK][KP]    their gradients, per slot, summed over the slot's sub-samples
   float *bsl = vcf + BLK * KP;        // [SLOTS][2][nk4] time-blended bases of the sub-sample each wave is working on / will work on next
   float *red = bsl + 2 * SLOTS * nk4; // [SLOTS][nop] per-wave reduction slab (+ dump slot)
   constexpr int NACC = nacc_of(MFMA);
@@ -91,7 +99,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   float *svec = accs + BLK * NACC;    // [BLK][9]     K > 8 only: (v_transl 3, v_r6 6) of every lane, MFMA B operand
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = wv / SL, slot = wv - sub * SL;  // this wave: sub-sample slot `slot` of sub-group `sub`
   const bool raw = d.flags & D4GS_RAW_PARAMS;
   const bool has_cam = MODE == MODE_RENDER || a.in.viewmat != nullptr;
   Cam cam;
@@ -99,14 +108,15 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   // Persistent blocks: block b walks the groups b, b + gridDim.x, ... and adds every group's shared-gradient sums into
   // wacc (each (sub-sample, element) is owned by one wave, the groups come in a fixed order -> deterministic); ONE partial
   // vector per block leaves the kernel instead of one per group (cfg5: 120 MB of partials written and read back).
-  float *wacc = svec + (MFMA ? BLK * 9 : 0);  // [n_shared], persist only
+  float *wacc = svec + (MFMA ? BLK * 9 : 0);  // [NSG][n_shared], persist only
   if (a.persist) {
-    for (int o = tid; o < a.n_shared; o += BLK) wacc[o] = 0.f;
+    for (int o = tid; o < NSG * a.n_shared; o += BLK) wacc[o] = 0.f;
   }
-  const int ngroups = (N + GPB - 1) / GPB;
+  const int ngroups = (N + NSG * GPB - 1) / (NSG * GPB);
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-  const int g = grp * GPB + lane;
-  const bool dyn_block = (grp * GPB) < G;
+  const int g = (grp * NSG + sub) * GPB + lane;
+  const bool dyn_block = ((grp * NSG + sub) * GPB) < G;  // (wave-uniform: the property of this wave's 64 Gaussians)
+  float *cfl = cf + (sub * GPB + lane) * KP;             // this lane's coefficient row
   const bool active = g < N;
   const bool isdyn = active && g < G;
 
@@ -128,9 +138,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   if (dyn_block) {
     for (int k = 0; k < K; k++) vcf[tid * KP + k] = 0.f;
     if (slot == 0) {  // softmax(motion_coefs) params.py:43, once per Gaussian
-      for (int k = 0; k < K; k++) cf[lane * KP + k] = 0.f;
+      for (int k = 0; k < K; k++) cfl[k] = 0.f;
       if (MODE == MODE_POSES && isdyn && !raw) {  // activated coefficients, used as given
-        for (int k = 0; k < K; k++) cf[lane * KP + k] = a.in.motion_coefs[(size_t)g * K + k];
+        for (int k = 0; k < K; k++) cfl[k] = a.in.motion_coefs[(size_t)g * K + k];
       } else if (isdyn) {
         const float *mc = a.in.motion_coefs + (size_t)g * K;
         float m = -INFINITY;
@@ -138,11 +148,11 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
         float sum = 0.f;
         for (int k = 0; k < K; k++) {
           float e = expf(mc[k] - m);
-          cf[lane * KP + k] = e;
+          cfl[k] = e;
           sum += e;
         }
         float is = 1.f / sum;
-        for (int k = 0; k < K; k++) cf[lane * KP + k] *= is;
+        for (int k = 0; k < K; k++) cfl[k] *= is;
       }
     }
   }
@@ -156,8 +166,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   float v_view_r[MFMA ? 12 : 1];
 #pragma unroll
   for (int c = 0; c < (MFMA ? 12 : 1); c++) v_view_r[c] = 0.f;
-  float *part = a.persist ? wacc : a.g.partials + (size_t)grp * a.n_shared;
-  float *mine = red + slot * nop;
+  float *part = a.persist ? wacc + sub * a.n_shared : a.g.partials + ((size_t)grp * NSG + sub) * a.n_shared;
+  float *mine = red + wv * nop;
 
   // Time-blended bases of sub-sample s (params.py:152-177; w uses the clamped floor): element idx = lane + 64 m of the
   // wave's [K][9] slab.  The loads for the NEXT sub-sample of this slot are issued at the top of a pass and the slab is
@@ -197,14 +207,14 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   int cur = 0;
   if (dyn_block && slot < S) {
     bases_load(slot);
-    bases_store(bsl + (slot * 2) * nk4);
+    bases_store(bsl + (wv * 2) * nk4);
   }
 
-  for (int s = slot; s < S; s += SLOTS, cur ^= 1) {  // wave-uniform
-    const float *B = bsl + (slot * 2 + cur) * nk4;
-    const bool more = dyn_block && s + SLOTS < S;
+  for (int s = slot; s < S; s += SL, cur ^= 1) {  // wave-uniform
+    const float *B = bsl + (wv * 2 + cur) * nk4;
+    const bool more = dyn_block && s + SL < S;
     __builtin_amdgcn_wave_barrier();
-    if (more) bases_load(s + SLOTS);
+    if (more) bases_load(s + SL);
     float vec[21];  // v9 adjoint (transl 3 + r6 6) + camera-delta adjoint 12
 #pragma unroll
     for (int r = 0; r < 21; r++) vec[r] = 0.f;
@@ -232,7 +242,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
 #pragma unroll
         for (int j = 0; j < 9; j++) v9[j] = 0.f;
         for (int k = 0; k < K; k++) {
-          float c = cf[lane * KP + k];
+          float c = cfl[k];
 #pragma unroll
           for (int j = 0; j < 9; j++) v9[j] += c * B[k * 9 + j];
         }
@@ -489,7 +499,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
       if (dyn) {
         if (dyn_block && !MFMA) {  // few bases: K x (9 multiplies + a 9-value wave reduction) on the VALU
           for (int k = 0; k < K; k++) {
-            const float c = cf[lane * KP + k];
+            const float c = cfl[k];
             float p[9];
 #pragma unroll
             for (int jj = 0; jj < 9; jj++) p[jj] = c * vec[jj];
@@ -510,8 +520,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
 #pragma unroll 4
             for (int kk = 0; kk < 16; kk++) {
               const int src = 4 * kk + lk;  // the Gaussian (lane of this wave) this operand element belongs to
-              const float av = am ? cf[src * KP + mt + ln] : 0.f;
-              const float bv = ln < 9 ? svec[(slot * 64 + src) * 9 + ln] : 0.f;
+              const float av = am ? cf[(sub * GPB + src) * KP + mt + ln] : 0.f;
+              const float bv = ln < 9 ? svec[(wv * 64 + src) * 9 + ln] : 0.f;
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
             }
             if (ln < 9) {
@@ -540,7 +550,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (more) bases_store(bsl + (slot * 2 + (cur ^ 1)) * nk4);
+    if (more) bases_store(bsl + (wv * 2 + (cur ^ 1)) * nk4);
   }
 
   // ---- viewmat partials (12 plain column sums): per-wave ladder + fixed-order sum of the 4 slots ----
@@ -554,18 +564,25 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
     wave_sum_store(v_view, mine, 0, lane);
   }
   __syncthreads();
-  if (tid < 12) {
+  if (tid < 12) {  // (wave 0 = sub-group 0: the block's view-matrix sum rides in ITS partial vector, zeros in the others')
     const float v = (red[tid] + red[nop + tid]) + (red[2 * nop + tid] + red[3 * nop + tid]);
     if (a.persist) part[S * no + tid] += v;
-    else part[S * no + tid] = v;
+    else {
+      part[S * no + tid] = v;
+      for (int u = 1; u < NSG; u++) part[(size_t)u * a.n_shared + S * no + tid] = 0.f;
+    }
   }
 
   if (active) {
-  // sum of the 4 slots' accumulators of Gaussian `lane`, fixed order
+  // sum of the sub-group's SL slots' accumulators of Gaussian `lane`, fixed order
+  const int row0 = sub * SL * 64 + lane;  // the row of slot 0 in the [BLK][.] per-lane arrays
   auto slots4 = [&](int c) {
-    return (accs[lane * NACC + c] + accs[(64 + lane) * NACC + c]) + (accs[(128 + lane) * NACC + c] + accs[(192 + lane) * NACC + c]);
+    const float *p = accs + row0 * NACC + c;
+    if (SL == 4) return (p[0] + p[64 * NACC]) + (p[128 * NACC] + p[192 * NACC]);
+    if (SL == 2) return p[0] + p[64 * NACC];
+    return p[0];
   };
-  // ---- per-Gaussian leaves: the block's 4 waves split the tensors ----
+  // ---- per-Gaussian leaves: the sub-group's SL waves split the four tensor groups (group p goes to slot p % SL) ----
   if (slot == 0) {
     a.g.v_means[g * 3] = slots4(0), a.g.v_means[g * 3 + 1] = slots4(1), a.g.v_means[g * 3 + 2] = slots4(2);
     if (MODE == MODE_RENDER) {
@@ -575,7 +592,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
         a.g.v_scales[g * 3 + j] = raw ? v : v / sc[j];
       }
     }
-  } else if (slot == 1) {
+  }
+  if (slot == 1 % SL) {
     if (need_q && a.g.v_quats) {  // adjoint of q / max(|q|, eps)
       const float w = qh[0], x = qh[1], y = qh[2], z = qh[3];
       const float vq0 = slots4(3), vq1 = slots4(4), vq2 = slots4(5), vq3 = slots4(6);
@@ -584,19 +602,22 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
                               (vq3 - dot * z) * inv_qn);
       *reinterpret_cast<float4 *>(a.g.v_quats + (size_t)g * 4) = o4;
     }
-  } else if (slot == 2) {
+  }
+  if (slot == 2 % SL) {
     if (isdyn) {  // softmax adjoint
       const bool act = MODE == MODE_POSES && !raw;
       float dot = 0.f;
+      float *vr = vcf + row0 * KP;
       for (int k = 0; k < K; k++) {
-        const float v = (vcf[lane * KP + k] + vcf[(64 + lane) * KP + k]) + (vcf[(128 + lane) * KP + k] + vcf[(192 + lane) * KP + k]);
-        vcf[lane * KP + k] = v;  // (only this lane touches row `lane` from here on)
-        dot += cf[lane * KP + k] * v;
+        const float v = SL == 4 ? (vr[k] + vr[64 * KP + k]) + (vr[128 * KP + k] + vr[192 * KP + k]) : SL == 2 ? vr[k] + vr[64 * KP + k] : vr[k];
+        vr[k] = v;  // (only this lane touches its slot-0 row from here on)
+        dot += cfl[k] * v;
       }
       for (int k = 0; k < K; k++)
-        a.g.v_motion_coefs[(size_t)g * K + k] = act ? vcf[lane * KP + k] : cf[lane * KP + k] * (vcf[lane * KP + k] - dot);
+        a.g.v_motion_coefs[(size_t)g * K + k] = act ? vr[k] : cfl[k] * (vr[k] - dot);
     }
-  } else if (MODE == MODE_RENDER) {
+  }
+  if (slot == 3 % SL && MODE == MODE_RENDER) {
     const float o = a.opac_act[g];
     const float vo = a.v_opac_act[g];
     a.g.v_opacities[g] = raw ? vo * o * (1.f - o) : vo;
@@ -614,8 +635,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   __syncthreads();  // cf / vcf / accs / red are rewritten by the next group
   }  // groups
   if (a.persist) {
-    float *dst = a.g.partials + (size_t)blockIdx.x * a.n_shared;
-    for (int o = tid; o < a.n_shared; o += BLK) dst[o] = wacc[o];
+    float *dst = a.g.partials + (size_t)blockIdx.x * NSG * a.n_shared;
+    for (int o = tid; o < NSG * a.n_shared; o += BLK) dst[o] = wacc[o];
   }
 }
 
@@ -732,9 +753,18 @@ static int resident_blocks(const void *fn, size_t lds) {
   return cus * per;
 }
 
+template <int MODE>
+static const void *kernel_of(bool mfma, int sl) {
+  if constexpr (MODE == MODE_RENDER) {
+    if (sl == 1) return mfma ? (const void *)k_project_bwd<MODE, true, 1> : (const void *)k_project_bwd<MODE, false, 1>;
+    if (sl == 2) return mfma ? (const void *)k_project_bwd<MODE, true, 2> : (const void *)k_project_bwd<MODE, false, 2>;
+  }
+  return mfma ? (const void *)k_project_bwd<MODE, true, 4> : (const void *)k_project_bwd<MODE, false, 4>;
+}
+
 // launch shape of k_project_bwd for one configuration: grid, LDS bytes, persistent or one group per block
 struct BwdPlan {
-  int blocks, persist;
+  int blocks, persist, sl, nparts;  // nparts: shared-gradient partial vectors the launch leaves (blocks x sub-groups)
   size_t lds;
   const void *fn;
 };
@@ -745,12 +775,14 @@ static BwdPlan plan_bwd(const D4gsDims *dims) {
   const int KP = K | 1;
   const size_t nk = (size_t)K * 9;
   const int n_shared = n_shared_of(dims);
-  p.fn = K > 8 ? (const void *)k_project_bwd<MODE, true> : (const void *)k_project_bwd<MODE, false>;
+  p.sl = slots_of<MODE>(dims->S);
+  p.fn = kernel_of<MODE>(K > 8, p.sl);
+  const int nsg = SLOTS / p.sl;
   auto lds_of = [&](bool persist) {
-    return sizeof(float) * ((size_t)GPB * KP + (size_t)BLK * KP + 2 * SLOTS * ((nk + 3) & ~(size_t)3) + SLOTS * (nk + 13) +
-                            (size_t)BLK * nacc_of(K > 8) + (K > 8 ? (size_t)BLK * 9 : 0) + (persist ? (size_t)n_shared : 0));
+    return sizeof(float) * ((size_t)nsg * GPB * KP + (size_t)BLK * KP + 2 * SLOTS * ((nk + 3) & ~(size_t)3) + SLOTS * (nk + 13) +
+                            (size_t)BLK * nacc_of(K > 8) + (K > 8 ? (size_t)BLK * 9 : 0) + (persist ? (size_t)nsg * n_shared : 0));
   };
-  p.blocks = (dims->N + GPB - 1) / GPB;
+  p.blocks = (dims->N + nsg * GPB - 1) / (nsg * GPB);
   p.persist = 0;
   p.lds = lds_of(false);
   if (n_shared <= PERSIST_MAX_SHARED) {
@@ -763,12 +795,13 @@ static BwdPlan plan_bwd(const D4gsDims *dims) {
     const bool uniform = dims->G == 0 || dims->G == dims->N;
     if (res > 0 && p.blocks >= (uniform ? 2 : 8) * res) p.blocks = res, p.persist = 1, p.lds = lds_of(true);
   }
+  p.nparts = p.blocks * nsg;
   return p;
 }
 
 extern "C" size_t d4gs_bwd_partials_elems(const D4gsDims *d) {
   // (the render and the poses instantiation have different register counts: take the larger grid of the two)
-  const int b0 = plan_bwd<MODE_RENDER>(d).blocks, b1 = plan_bwd<MODE_POSES>(d).blocks;
+  const int b0 = plan_bwd<MODE_RENDER>(d).nparts, b1 = plan_bwd<MODE_POSES>(d).nparts;
   return ((size_t)(b0 > b1 ? b0 : b1) + RCH + 1) * (size_t)n_shared_of(d);
 }
 
@@ -777,7 +810,6 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   a.n_shared = n_shared_of(dims);
   const BwdPlan pl = plan_bwd<MODE>(dims);
   a.persist = pl.persist;
-  const int K = dims->G > 0 ? dims->K : 0;
   const size_t lds = pl.lds;
   const int blocks = pl.blocks;
   if (lds > 160 * 1024) {
@@ -787,14 +819,17 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   if (lds > 64 * 1024)  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
     (void)hipFuncSetAttribute(pl.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const char *name = MODE == MODE_RENDER ? "k_project_bwd" : "k_project_bwd[poses]";
-  if (K > 8) D4GS_LAUNCH(name, (k_project_bwd<MODE, true>), dim3(blocks), dim3(BLK), lds, stream, a);
-  else D4GS_LAUNCH(name, (k_project_bwd<MODE, false>), dim3(blocks), dim3(BLK), lds, stream, a);
+  {
+    ProfScope _ps(name, stream);
+    void *kargs[] = {(void *)&a};
+    (void)hipLaunchKernel(pl.fn, dim3(blocks), dim3(BLK), kargs, lds, stream);
+  }
   int rc = d4gs_check_launch(name);
   if (rc) return rc;
-  float *red2 = grads->partials + (size_t)blocks * a.n_shared;  // [RCH][n_shared] chunk sums, then [n_shared] totals
+  float *red2 = grads->partials + (size_t)pl.nparts * a.n_shared;  // [RCH][n_shared] chunk sums, then [n_shared] totals
   float *red = red2 + (size_t)RCH * a.n_shared;
   D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256, RCH), dim3(256), 0, stream,
-              (const float *)grads->partials, blocks, a.n_shared, red2);
+              (const float *)grads->partials, pl.nparts, a.n_shared, red2);
   D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256, 1), dim3(256), 0, stream,
               (const float *)red2, RCH, a.n_shared, red);
   int fin = dims->G > 0 ? dims->K * dims->T * 9 : 0;

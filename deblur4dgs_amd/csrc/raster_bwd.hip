@@ -37,6 +37,7 @@ struct RasterBwdArgs {
   int sparse;            // 0: every row is written (rows behind a tile's last contributor are zero-filled), no flags
   const int64_t *n_dev;  // device {total, longest list}; the lists were sized for (cap, max_hint) - see binning.hip
   int64_t cap, max_hint;
+  const float *seg_state;  // SEG instantiations: the forward's per-pixel state at the depth-segment boundaries (common.h)
 };
 
 // The forward stage skips its work when the device-side intersection count exceeds what the caller sized the lists for
@@ -71,7 +72,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // amdgpu_waves_per_eu(8, 8): the kernel's time follows ~ 415 us + 2000 us / (waves per SIMD) on cfg2 (measured by padding the
 // workgroup's LDS: 2 -> 1413, 3 -> 1034, 4 -> 863, 7 -> 700 us); asked for 8 the compiler fits D <= 5 in 52-64 VGPRs without
 // scratch (68 before: 7 waves): 700 -> 687 us.  The wide instantiations (D = 8, 16) keep their registers - the hint cannot be met.
-template <int D, bool DEPTH>
+// SEG (round 4, few-tile launches): one workgroup per (tile, depth segment) instead of per tile.  A segment [lo, hi_ex) of the
+// list is replayed exactly like a whole list, except that a pixel whose last contributor lies BEHIND the segment does not start
+// from (final T, empty suffix) but from the state the sequential replay would have when it arrives at hi_ex - 1: the
+// transmittance the forward stored at that boundary and the suffix dot product <v_out, C_final - C_boundary> (what `bsum` has
+// accumulated by then).  Rows are still written once, by the segment that owns them: no atomics, run-to-run deterministic;
+// against the unsegmented replay the gradients differ by the fp32 rounding of that hand-off.
+template <int D, bool DEPTH, bool SEG = false>
 __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
 #pragma clang fp contract(off)
   constexpr int NCH = D + (DEPTH ? 1 : 0);
@@ -102,9 +109,15 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
   if (lists_overflowed(a.n_dev, a.cap, a.max_hint)) return;
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
-  const int t = xcd_remap_b(blockIdx.x, n_tiles);
+  const int lb = xcd_remap_b(blockIdx.x, SEG ? n_tiles * D4GS_SEG_MAX : n_tiles);  // (a tile's segments stay on one XCD)
+  const int t = SEG ? lb / D4GS_SEG_MAX : lb, seg = SEG ? lb - t * D4GS_SEG_MAX : 0;
   if (t >= n_tiles) return;
-  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
+  int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
+  if constexpr (SEG) {  // from here on [start, end) is this workgroup's segment of the list
+    const int sl = d4gs_seg_len(end - start);
+    start += seg * sl;
+    end = min(start + sl, end);
+  }
   if (end <= start) return;
   const int s = t / n_tiles_s, tl = t - s * n_tiles_s;
   const int ty = tl / a.tw, tx = tl - ty * a.tw;
@@ -141,6 +154,16 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
     }
     va = Tfin * (v_al - bgdot);
     T = Tfin;
+    if constexpr (SEG) {
+      if (last >= end) {  // contributors behind this segment: take over at its back boundary (slot seg + 1; slot 0 = final state)
+        const float *sf = a.seg_state + (size_t)t * D4GS_SEG_MAX * (1 + NCH) * 256 + ((y - ty * D4GS_TILE) * D4GS_TILE + (x - tx * D4GS_TILE));
+        const float *sb = sf + (size_t)(seg + 1) * (1 + NCH) * 256;
+        T = sb[0];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) bsum = __builtin_fmaf(vo[c], sf[(1 + c) * 256] - sb[(1 + c) * 256], bsum);
+        last = end - 1;
+      }
+    }
   }
   // last contributor of this quadrant / of the tile
   int whi = last < start ? start - 1 : last;
@@ -331,6 +354,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 template <int D, bool DEPTH>
 __global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
   raster_bwd_q_body<D, DEPTH>(a);
+}
+// the same two over (tile, depth segment) workgroups
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_raster_bwd_qs8(const RasterBwdArgs a) {
+  raster_bwd_q_body<D, DEPTH, true>(a);
+}
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) k_raster_bwd_qs(const RasterBwdArgs a) {
+  raster_bwd_q_body<D, DEPTH, true>(a);
 }
 
 #ifdef D4GS_VARIANTS
@@ -646,7 +678,11 @@ int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, 
         return D4GS_ELAUNCH;
       }
     }
-    if (n_isect > 0) {
+    if (n_isect > 0 && a.seg_state) {
+      const int sblocks = ((n_tiles * D4GS_SEG_MAX + 7) / 8) * 8;
+      if constexpr (D <= 5) D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_qs8<D, DEPTH>), dim3(sblocks), dim3(256), 0, stream, a);
+      else D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_qs<D, DEPTH>), dim3(sblocks), dim3(256), 0, stream, a);
+    } else if (n_isect > 0) {
       if constexpr (D <= 5) D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q8<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
       else D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
     }
@@ -674,6 +710,7 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad, a.live = g->isect_live;
   a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
+  a.seg_state = d4gs_seg_on(dims, isect, r) ? r->seg_state : nullptr;
   GatherArgs ga;
   ga.n_dev = proj->n_isect, ga.cap = isect->n_isect, ga.max_hint = isect->max_tile_count;
   ga.rows = isect->n_isect > 0 ? isect->n_isect : 1;

@@ -32,6 +32,7 @@ struct RasterFwdArgs {
   int64_t *n_dev;  // device {total, longest list, sampled entries, sampled live entries}: [0], [1] vs the capacity the lists were
                    // sized for (see binning.hip); [2], [3]: this kernel's live-row sample
   int64_t cap, max_hint;
+  float *seg_state;  // SEG instantiations: [tiles][D4GS_SEG_MAX][1 + NCH][256] boundary states (common.h "depth segments")
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n_blocks) {
@@ -81,7 +82,7 @@ template <> struct BoxT<false> {
   static __device__ __forceinline__ float4 unpack(float4 p) { return p; }
 };
 
-template <int D, bool DEPTH>
+template <int D, bool DEPTH, bool SEG = false>
 __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 #pragma clang fp contract(off)
   constexpr int NCH = D + (DEPTH ? 1 : 0);
@@ -126,6 +127,18 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 
   const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   const size_t inst_base = (size_t)s * a.N;
+  // SEG: the pixel's state (T, accumulated channels) is stored at every depth-segment boundary of the list and at its end, in
+  // tile-local pixel order, for the segmented backward (raster_bwd.hip).  Slot 0 = final state, slot k = after k * seglen entries.
+  const int seglen = SEG ? d4gs_seg_len(end - start) : 0;
+  float *seg_px = SEG ? a.seg_state + (size_t)t * D4GS_SEG_MAX * (1 + NCH) * 256 + ((y - ty * D4GS_TILE) * D4GS_TILE + (x - tx * D4GS_TILE)) : nullptr;
+  auto seg_store = [&](int k) {
+    if (inside) {
+      float *p = seg_px + (size_t)k * (1 + NCH) * 256;
+      p[0] = T;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) p[(1 + c) * 256] = acc[c];
+    }
+  };
   for (int b = start; b < end; b += FB) {
     if (__syncthreads_and(done)) break;  // also orders the previous batch's LDS reads before restaging
     const int idx = b + tid;
@@ -208,7 +221,12 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     }
     last = lastj >= 0 ? b + lastj : last;  // list index of the batch's last contributor, formed once per batch
     has_last = has_last || lastj >= 0;
+    if constexpr (SEG) {
+      const int e = b + FB - start;  // entries composited so far (a boundary is never the end of the list: slot 0 holds that)
+      if (e < end - start && e % seglen == 0) seg_store(e / seglen);
+    }
   }
+  if constexpr (SEG) seg_store(0);
 
   // live-row sample (include/d4gs.h, D4gsProjOut.n_isect[2..3]): every `stride`-th tile adds its list length and the entries
   // up to its last contributor - at most 128 tiles, so the device-scope atomics never queue up
@@ -248,6 +266,15 @@ template <int D, bool DEPTH>
 __global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
   raster_fwd_r_body<D, DEPTH>(a);
 }
+// the same two, also storing the segment-boundary states (few-tile launches; the kernels above stay as they are)
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_raster_fwd_rs8(const RasterFwdArgs a) {
+  raster_fwd_r_body<D, DEPTH, true>(a);
+}
+template <int D, bool DEPTH>
+__global__ void __launch_bounds__(256) k_raster_fwd_rs(const RasterFwdArgs a) {
+  raster_fwd_r_body<D, DEPTH, true>(a);
+}
 
 template <int D, bool DEPTH>
 int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
@@ -265,12 +292,38 @@ int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
     return d4gs_check_launch("k_raster_fwd_q");
   }
 #endif
+  if (a.seg_state) {
+    if constexpr (D <= 4) D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_rs8<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+    else D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_rs<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+    return d4gs_check_launch("k_raster_fwd_r");
+  }
   if constexpr (D <= 4) D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r8<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
   else D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
   return d4gs_check_launch("k_raster_fwd_r");
 }
 
 }  // namespace
+
+// ---- depth segments: when, and how much state (common.h) ----
+int64_t d4gs_seg_state_elems(const D4gsDims *d) {
+  const int64_t tw = (d->width + D4GS_TILE - 1) / D4GS_TILE, th = (d->height + D4GS_TILE - 1) / D4GS_TILE;
+  const int64_t n_tiles = (int64_t)d->S * tw * th;
+  if (n_tiles > D4GS_SEG_TILES_MAX) return 0;
+  const int64_t nch = d->D + (d->depth_mode != D4GS_DEPTH_NONE ? 1 : 0);
+  return n_tiles * D4GS_SEG_MAX * (1 + nch) * 256;
+}
+bool d4gs_seg_on(const D4gsDims *d, const D4gsIsect *isect, const D4gsRaster *r) {
+  static const char *env = getenv("D4GS_SEG");  // "0": never, "1": whenever the buffer is there (tests); default: see below
+  if (!r->seg_state || d4gs_seg_state_elems(d) == 0 || (env && env[0] == '0')) return false;
+#ifdef D4GS_VARIANTS  // the environment-selected reference variants neither write nor read the boundary states
+  if (getenv("D4GS_FWD_WAVE_PER_TILE") || getenv("D4GS_FWD_QUADS") || getenv("D4GS_BWD_WAVE_PER_TILE") || getenv("D4GS_BWD_MFMA"))
+    return false;
+#endif
+  if (env && env[0] == '1') return true;
+  // worth it only when some list spans more than one segment; the longest list is known from the previous render of the
+  // shape (D4gsIsect.max_tile_count; <= 0 = unknown).  Forward and backward of one render see the same D4gsIsect.
+  return isect->max_tile_count > D4GS_SEG_UNIT;
+}
 
 int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
                          hipStream_t stream) {
@@ -283,6 +336,7 @@ int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.tile_offsets = proj->tile_offsets, a.sorted_gid = isect->sorted_gid;
   a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
+  a.seg_state = d4gs_seg_on(dims, isect, r) ? r->seg_state : nullptr;
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
 #define D4GS_CASE(DD)                                                   \
   case DD:                                                              \

@@ -506,6 +506,20 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
     return n, max_tile
 
 
+_SEG_ELEMS: dict = {}
+
+
+def seg_state_elems(cfg: RenderCfg) -> int:
+    """D4gsSizes.seg_state of the configuration (0: the composite does not use depth segments for it)."""
+    key = (cfg.S, cfg.width, cfg.height, cfg.D, cfg.depth_mode)
+    n = _SEG_ELEMS.get(key)
+    if n is None:
+        z = L.Sizes()
+        L.check(L.lib().d4gs_query_sizes(C.byref(cfg.dims()), C.byref(z)), "d4gs_query_sizes")
+        n = _SEG_ELEMS[key] = int(z.seg_state)
+    return n
+
+
 class RasterFn(torch.autograd.Function):
     """Composite one channel chunk.  `cfg` is the chunk's configuration (its D = the kernel width, depth mode set on
     the last chunk only); the projection outputs and the sorted tile lists come from the shared `st`.  The first chunk
@@ -524,10 +538,14 @@ class RasterFn(torch.autograd.Function):
                    render_alphas=torch.empty(S, H, W, **f32), last_ids=torch.empty(S, H, W, **i32),
                    final_T=torch.empty(S, H, W, **f32))
         dims = cfg.dims()
+        n_seg = seg_state_elems(cfg)  # few-tile launches: per-pixel states at depth-segment boundaries (D4gsRaster.seg_state)
+        rst["seg_state"] = torch.empty(n_seg, **f32) if n_seg > 0 else None
         pout = L.fill(L.ProjOut(), **{**st.proj_out, "ctab": ctab})
         ras = L.fill(L.Raster(), **rst)
+        hint_used = [0]
 
         def raster(cap, max_hint):
+            hint_used[0] = max_hint
             isect = L.fill(L.Isect(), **st.isect)
             isect.n_isect, isect.max_tile_count = max(cap, 1), max_hint
             L.check(lib.d4gs_raster_fwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), _stream()),
@@ -549,6 +567,7 @@ class RasterFn(torch.autograd.Function):
             st.binned = True
             st.raster = rst
         ctx.st, ctx.cfg, ctx.rst, ctx.ctab = st, cfg, rst, ctab
+        ctx.max_hint = hint_used[0]  # the longest-list bound the forward composited under: the backward must see the same one
         return rst["render_colors"].view(S, H, W, cfg.NCH), rst["render_alphas"].unsqueeze(-1)
 
     @staticmethod
@@ -573,7 +592,7 @@ class RasterFn(torch.autograd.Function):
         dims = cfg.dims()
         pout = L.fill(L.ProjOut(), **{**st.proj_out, "ctab": ctx.ctab})
         isect = L.fill(L.Isect(), **st.isect)
-        isect.n_isect, isect.max_tile_count = st.n_isect, st.max_tile
+        isect.n_isect, isect.max_tile_count = st.n_isect, ctx.max_hint  # (segments on / off follow it: D4gsRaster.seg_state)
         ras = L.fill(L.Raster(), **rst)
         rg = L.fill(L.RasterGrads(), **g)
         rg.row_mode = row_mode_for(cfg, dev)

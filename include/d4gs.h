@@ -135,6 +135,14 @@ typedef struct D4gsRaster {
   float *final_T;          /* [S,H,W] transmittance left behind the last splat.  The backward starts from this instead
                               of 1 - render_alphas (as gsplat does): for nearly opaque pixels (T ~ 1e-4) the fp32
                               subtraction loses ~3 digits, which shows up as a ~5e-4 relative bias of the gradients. */
+  float *seg_state;        /* [D4gsSizes.seg_state] scratch or NULL.  Few-tile launches (S * tiles <= 1280: one or two exposure
+                              sub-samples of a 288x512 frame, i.e. a rank of BASELINE config 4) cannot fill 256 CUs with one
+                              workgroup per tile; given this buffer, d4gs_raster_fwd also stores every pixel's transmittance and
+                              accumulated channels at up to 7 depth-segment boundaries of its tile list (+ the final ones) and
+                              d4gs_raster_bwd replays the segments in parallel workgroups, each starting from the stored state.
+                              Same image bit for bit; gradients equal to the unsegmented replay up to fp32 rounding of the
+                              hand-off (deterministic).  NULL, or a configuration whose seg_state size is 0: one workgroup per
+                              tile as before.  The SAME value must be passed to the forward and its backward. */
 } D4gsRaster;
 
 /* gradients w.r.t. the raster stage's per-instance inputs */
@@ -201,9 +209,10 @@ size_t d4gs_bwd_partials_elems(const D4gsDims *dims);
 typedef struct {
   int64_t means2d, depths, conics, radii, opac_act, ctab, geom, tile_rects, tiles_touched, isect_offsets;
   int64_t tile_counts, tile_offsets, n_isect, scan_ws;          /* D4gsProjOut */
-  int64_t render_colors, render_alphas, last_ids, final_T;       /* D4gsRaster */
+  int64_t render_colors, render_alphas, last_ids, final_T;       /* D4gsRaster (seg_state: last field of this struct) */
   int64_t isect_grad_row;                                        /* floats per intersection in isect_grad (isect_live: 1 byte) */
   int64_t bwd_partials;                                          /* D4gsLeafGrads.partials */
+  int64_t seg_state;                                             /* D4gsRaster.seg_state; 0 = this configuration does not use depth segments */
   int32_t tiles_x, tiles_y, channels;                            /* tile grid; D + depth channel */
 } D4gsSizes;
 int d4gs_query_sizes(const D4gsDims *dims, D4gsSizes *sizes);

@@ -48,5 +48,17 @@ for P in (1, 2, 4, 8):
         g.replay()
     torch.cuda.synchronize()
     dg = (time.perf_counter() - t0) / 50
+    lib = __import__("deblur4dgs_amd._lib", fromlist=["lib"]).lib()
+    import ctypes as C
+    lib.d4gs_profile_enable(1)
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    lib.d4gs_profile_enable(0)
+    buf = C.create_string_buffer(1 << 16)
+    lib.d4gs_profile_collect(buf, C.c_size_t(len(buf)))
+    rows = sorted(((ln.split()[0], float(ln.split()[2]) / 10) for ln in buf.value.decode().splitlines()), key=lambda r: -r[1])
+    kern = ", ".join(f"{n} {1e3 * ms:.0f}" for n, ms in rows)
+    print(f"P={P}: kernels (us per step, HIP events, eager): {kern}; sum {1e3 * sum(ms for _, ms in rows):.0f}")
     print(f"P={P}: rank 0 renders {len(range(0, S, P))} of {S} sub-samples: {1e3 * dt:.3f} ms per step eager, {1e3 * dg:.3f} ms from a HIP graph "
           f"(no collectives) -> at most {1.403e-3 / dg if P > 1 else 1.0:.2f}x")

@@ -30,7 +30,12 @@ def _split(sc, dtype):
                                                     (1000, 600, 5, 2, 72, 40, False, False),
                                                     # the reference's defaults: 20 bases, 11 sub-samples
                                                     (700, 300, 20, 11, 64, 48, True, True),
-                                                    (500, 500, 32, 16, 48, 48, False, True)])
+                                                    (500, 500, 32, 16, 48, 48, False, True),
+                                                    # small S: k_project_bwd's sub-group mapping (4 / 2 groups of 64 Gaussians per
+                                                    # block), on the VALU (K <= 8) and on the matrix pipe (K > 8), ragged N / G
+                                                    (1100, 700, 6, 1, 80, 48, False, True),
+                                                    (1000, 1000, 12, 1, 64, 48, True, True),
+                                                    (900, 500, 20, 2, 64, 48, False, True)])
 def test_exposure_forward_backward(N, G, K, S, W, H, mask, depth):
     from deblur4dgs_amd.exposure import render_exposure
 
