@@ -89,6 +89,14 @@ def parse():
                     help="capture one step (render forward + backward, deferred size check) in a HIP graph and time its "
                          "replays (with --gpus N > 1 / --force-dist the RCCL collectives are captured too: verified at world size 1 only)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL code path with world_size 1")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="run the N > 1 control flow of this script on CPU tensors over gloo (tests/test_parallel_gloo.py): "
+                         "process-group set-up, the sharded step's collectives, the graph-capture fallback agreement, max-over-ranks "
+                         "timing, ONE JSON line - with the render replaced by a synthetic differentiable image.  Measures nothing.")
+    ap.add_argument("--share", type=int, default=1, metavar="P",
+                    help="diagnostic (not the headline): render only rank 0's share {s : s %% P == 0} of the exposure sub-samples, no "
+                         "collectives - the device work ONE rank of an exposure-sharded frame at world size P executes "
+                         "(scripts/shard_floor.py; lets the profiling scripts look at the S / P kernels on one GPU)")
     return ap.parse_args()
 
 
@@ -328,8 +336,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dry = args.dry_run
+    if not dry:
+        torch.cuda.set_device(local)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
     # N > 1: the sharded step leaves each rank a fraction of a millisecond of device work behind ~1 ms of host launch work,
     # so the captured step (one hipGraphLaunch, RCCL collectives inside) is the default there; --no-graph times the eager one
@@ -342,28 +352,49 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the pool's driver only supports dmabuf IPC
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from deblur4dgs_amd import _lib as L
     from deblur4dgs_amd import engine
     from deblur4dgs_amd.exposure import render_exposure
     from deblur4dgs_amd.parallel import ShardedExposure
 
-    name = args.config
+    name = "tiny" if dry else args.config
     N, G, K, S, W, H = CONFIGS[name]
     channels = args.channels or (16 if name.startswith("refdefault") else 3)
     if use_dist and args.shard == "exposure" and world > S:
         raise SystemExit(f"--shard exposure needs world_size <= S ({world} > {S})")
     bg = torch.ones(channels, device=dev)
-    lib = L.lib()
-    prof = not args.no_profile and not args.graph  # HIP events cannot bracket kernels inside a replayed graph
+    lib = None if dry else L.lib()
+    prof = not args.no_profile and not args.graph and not dry  # HIP events cannot bracket kernels inside a replayed graph
 
     def sync():
         if use_dist:
             import torch.distributed as dist
 
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
+
+    def dry_render(means, quats, scales, opacities, colors, n_sig, motion_coefs, rots, transls, times, RTs, viewmat, Kmat, Wd, Hd,
+                   background=None, blend=True, **_kw):
+        """--dry-run: a differentiable stand-in for render_exposure on CPU tensors - [S_loc, H, W, 4] images that depend on every
+        leaf, so the blend collectives and the gradient all-reduce carry real (if meaningless) data."""
+        import types
+
+        g = torch.Generator().manual_seed(11)
+        base = torch.rand(Hd, Wd, 4, generator=g)
+        per_g = sum(t.mean() for t in (means, quats, scales, opacities, colors, motion_coefs))
+        shared = rots.mean() + transls.mean() + viewmat.mean()
+        gain = torch.tanh(times + RTs.reshape(RTs.shape[0], -1).sum(-1))  # [S_loc]
+        renders = base[None] * (1.0 + 0.1 * gain.view(-1, 1, 1, 1)) + 0.01 * (per_g + shared)
+        alphas = torch.sigmoid(renders[..., :1].detach() * 0 + gain.view(-1, 1, 1, 1) + per_g)
+        st = types.SimpleNamespace(n_isect=0, cfg=types.SimpleNamespace(S=times.shape[0]))
+        return dict(renders=renders, alphas=alphas, state=st, blended=renders.mean(0) if blend else None,
+                    acc=alphas.mean(0)[..., 0] if blend else None)
 
     def collect():
         lib.d4gs_profile_enable(0)
@@ -400,16 +431,22 @@ def main():
             sys.stderr.write(f"d4gs_measure_peaks failed: {e!r}\n")
             return None
 
-    peaks = measured_peaks() if rank == 0 else None
+    peaks = measured_peaks() if rank == 0 and not dry else None
 
     def measure(mode, steps, warmup, profile):
         """-> (seconds for `steps` steps: max over ranks, live kernel timings, last state)"""
         views = use_dist and mode == "views"
         sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0, channels=channels,
                                                 scale_mul=args.scale_mul)
+        if args.share > 1 and not use_dist:
+            for k in ("times", "RTs"):
+                if k in leaves:
+                    leaves[k] = leaves[k][::args.share].detach().clone().requires_grad_()
         sharder = ShardedExposure(world, rank, mode=mode) if use_dist else None
         if sharder is not None:
             sharder.fused = not args.staged
+            if dry:
+                sharder.render = dry_render
         deferred = not args.sync_size_check
         if sharder is not None:
             sharder.deferred_size_check = deferred
@@ -429,7 +466,7 @@ def main():
                 last["st"] = res["state"]
             else:
                 last["st"] = sharder.step(leaves, d["K"], W, H, bg, wimg, wacc)
-            if mode_flag["deferred"]:
+            if mode_flag["deferred"] and not dry:
                 engine.check_deferred()  # this step's list sizes, verified behind its launches (raises on overflow)
 
         for _ in range(warmup):
@@ -444,8 +481,9 @@ def main():
             sync()
             real_state = last["st"]
             mode_flag["deferred"] = deferred
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
+            if not dry:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
 
             def gstep():
                 if sharder is not None:
@@ -461,23 +499,30 @@ def main():
                 loss.backward()
                 return res["state"]
 
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    gstep()
-            torch.cuda.current_stream().wait_stream(side)
+            if not dry:
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        gstep()
+                torch.cuda.current_stream().wait_stream(side)
             if sharder is None:
                 for v in leaves.values():
                     v.grad = None
-            graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
-                    gstep()
-                captured = True
+                if dry:  # (rank 0 of a dry run "cannot capture": the agreement below must send EVERY rank to the eager step)
+                    if rank == 0:
+                        raise RuntimeError("no HIP graphs in a CPU dry run")
+                    captured = True
+                else:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        gstep()
+                    captured = True
             except Exception as e:  # (never seen at world size 1; an N > 1 capture has not run on this pool's 1-GPU boxes)
                 captured = False
                 graph_note["fallback"] = f"graph capture failed ({type(e).__name__}: {e}); timed the eager step"
                 sys.stderr.write(graph_note["fallback"] + "\n")
-                torch.cuda.synchronize()
+                if not dry:
+                    torch.cuda.synchronize()
             if use_dist:  # every rank must take the same path: one that could not capture sends them all to the eager step
                 import torch.distributed as dist
 
@@ -487,6 +532,8 @@ def main():
                     captured = False
                     graph_note["fallback"] = "another rank could not capture its step; timed the eager step"
             if captured:
+                assert not dry, "a dry run never replays a graph: the cross-rank agreement failed"
+
                 def step():  # noqa: F811
                     graph.replay()
                     last["st"] = real_state  # exact list sizes of the same scene (the captured state holds capacities)
@@ -512,7 +559,7 @@ def main():
                 step()
             sync()
             kern_all = collect()
-        if not args.graph:  # one untimed STAGED step with host-checked sizes: its state carries the exact counts and the
+        if not args.graph and not dry:  # one untimed STAGED step with host-checked sizes: its state carries the exact counts and the
             mode_flag["deferred"] = False  # per-stage buffers (tile offsets, last ids) of the byte / pair accounting below
             mode_flag["fused"] = False
             if sharder is not None:
@@ -536,7 +583,7 @@ def main():
     out = {
         "metric": metric, "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if views_primary else "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "dry-run (CPU / gloo control-flow check, no kernels)" if dry else "synthetic",
         "config": {"workload": f"{name}: {N} Gaussians ({G} dynamic), {K} motion bases, {W}x{H}, N_exposure={S}, "
                                 f"{channels}+depth channels, fwd+bwd to all leaves"
                                 + (f", extents x{args.scale_mul:g}" if args.scale_mul != 1.0 else ""),
@@ -546,6 +593,9 @@ def main():
                     if not views_primary else f"views sharded x{world} (data parallel), RCCL gradient all-reduce")},
         "instances_per_s": value * S,
     }
+    if args.share > 1:
+        out["metric"] = f"DIAGNOSTIC rank-0 share of {name} at world size {args.share} (no collectives), Gaussians / t"
+        out["config"]["workload"] += f"; ONLY sub-samples s % {args.share} == 0 rendered (--share)"
     out["config"]["size_check"] = ("host waits for every render's intersection counts" if args.sync_size_check else
                                    "intersection counts verified once per step behind the launches (deferred)")
     if args.graph:
@@ -558,7 +608,9 @@ def main():
                                      "ms_per_step": 1e3 * dt_v / args.steps,
                                      "note": "every rank renders its own full frame (one camera view per GPU), flat "
                                              "gradient all-reduce; NOT BASELINE's cfg4"}
-    if rank == 0:
+    if rank == 0 and dry:
+        print(json.dumps(out))
+    elif rank == 0:
         n_isect = st.n_isect
         S_loc = st.cfg.S
         out["n_isect_per_step"] = n_isect if world == 1 else None

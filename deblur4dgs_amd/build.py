@@ -88,17 +88,20 @@ def build_variants() -> str:
 
 
 def build_ab(name: str, src: str, defines: list[str]) -> str:
-    """scripts/ablate/libd4gs_<name>.so: the product objects with `src` recompiled under extra -D flags (A/B timing of one
-    kernel on the GPU box: `D4GS_LIB_PATH=scripts/ablate/libd4gs_<name>.so python bench.py ...`)."""
+    """scripts/ablate/libd4gs_<name>.so: the product objects with `src` (one file, or several separated by commas) recompiled
+    under extra -D flags (A/B timing of one kernel on the GPU box: `D4GS_LIB_PATH=scripts/ablate/libd4gs_<name>.so python bench.py ...`)."""
     build()
     out_dir = os.path.join(HERE, "..", "scripts", "ablate")
     os.makedirs(out_dir, exist_ok=True)
-    obj = os.path.join(out_dir, f"ab_{name}.o")
-    cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(src, []), _cuid(src), *defines, "-c", os.path.join(CSRC, src), "-o", obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
-    objs = [obj if s == src else os.path.join(OBJ, s.replace(".hip", ".o")) for s in _sources()]
+    ab = {}
+    for one in src.split(","):
+        obj = os.path.join(out_dir, f"ab_{name}_{os.path.splitext(one)[0]}.o")
+        cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(one, []), _cuid(one), *defines, "-c", os.path.join(CSRC, one), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {one}:\n{r.stderr}")
+        ab[one] = obj
+    objs = [ab.get(s) or os.path.join(OBJ, s.replace(".hip", ".o")) for s in _sources()]
     lib = os.path.join(out_dir, f"libd4gs_{name}.so")
     r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
     if r.returncode != 0:

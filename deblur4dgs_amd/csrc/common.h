@@ -308,9 +308,15 @@ __device__ __forceinline__ void project_instance(const Cam &cam, const float *mw
 // the accumulated channels at every segment boundary (+ the final ones), from which a segment's workgroup starts exactly where
 // the sequential replay would be (T at the boundary; the suffix dot product <v_out, C_final - C_boundary>).
 // Segment length of a list of `len` entries: a multiple of 256 (= the forward's batch or twice it), at most D4GS_SEG_MAX segments.
+#ifndef D4GS_SEG_MAX  // (overridable for A/B builds: scripts/ab_run.sh)
 #define D4GS_SEG_MAX 8
+#endif
+#ifndef D4GS_SEG_UNIT
 #define D4GS_SEG_UNIT 256
+#endif
+#ifndef D4GS_SEG_TILES_MAX
 #define D4GS_SEG_TILES_MAX 1280  // S * tiles above this: the plain kernels already fill the machine (>= 5 waves per SIMD)
+#endif
 __host__ __device__ __forceinline__ int d4gs_seg_len(int len) {
   const int per = (len + D4GS_SEG_UNIT * D4GS_SEG_MAX - 1) / (D4GS_SEG_UNIT * D4GS_SEG_MAX);
   return D4GS_SEG_UNIT * (per > 1 ? per : 1);

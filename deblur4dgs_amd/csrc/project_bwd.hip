@@ -634,9 +634,15 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   }  // active
   __syncthreads();  // cf / vcf / accs / red are rewritten by the next group
   }  // groups
-  if (a.persist) {
-    float *dst = a.g.partials + (size_t)blockIdx.x * NSG * a.n_shared;
-    for (int o = tid; o < NSG * a.n_shared; o += BLK) dst[o] = wacc[o];
+  if (a.persist) {  // ONE partial vector per block: the sub-groups' sums added in fixed order
+    __syncthreads();
+    float *dst = a.g.partials + (size_t)blockIdx.x * a.n_shared;
+    for (int o = tid; o < a.n_shared; o += BLK) {
+      float v = wacc[o];
+#pragma unroll
+      for (int u = 1; u < NSG; u++) v += wacc[u * a.n_shared + o];
+      dst[o] = v;
+    }
   }
 }
 
@@ -666,7 +672,29 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float *partials, 
 // One thread per LEAF element (basis k, frame, component): it walks the sub-samples in order and adds the (1 - w) share
 // of those whose floor frame it is, then the w share of those whose ceil frame it is - independent loads, one store, no
 // read-modify-write chains through memory (the first version's (k, j) owners did S dependent global updates: 9 us).
-__global__ void __launch_bounds__(256) k_finish(const BwdArgs a, const float *red) {
+// `red_in`: n_in > 0: [n_in][n_shared] chunk sums of k_reduce_partials' first pass - every block first adds them (the second
+// pass's arithmetic and order, so the totals are the same bits) into LDS and works from there: one launch less per frame;
+// n_in == 0: the [n_shared] totals themselves, in global memory (shared vectors beyond the LDS budget).
+__global__ void __launch_bounds__(256) k_finish(const BwdArgs a, const float *red_in, int n_in) {
+  extern __shared__ __attribute__((aligned(16))) float sred[];
+  const float *red = red_in;
+  if (n_in > 0) {
+    const int n = a.n_shared;
+    for (int o = threadIdx.x; o < n; o += 256) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int b = 0;
+      for (; b + 3 < n_in; b += 4) {
+        a0 += red_in[(size_t)b * n + o];
+        a1 += red_in[(size_t)(b + 1) * n + o];
+        a2 += red_in[(size_t)(b + 2) * n + o];
+        a3 += red_in[(size_t)(b + 3) * n + o];
+      }
+      for (; b < n_in; b++) a0 += red_in[(size_t)b * n + o];
+      sred[o] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    red = sred;
+  }
   const D4gsDims &d = a.d;
   const int K = d.K, T = d.T, S = d.S;
   const bool dyn = d.G > 0;
@@ -794,8 +822,11 @@ static BwdPlan plan_bwd(const D4gsDims *dims) {
     const int res = resident_blocks(p.fn, lds_of(true));
     const bool uniform = dims->G == 0 || dims->G == dims->N;
     if (res > 0 && p.blocks >= (uniform ? 2 : 8) * res) p.blocks = res, p.persist = 1, p.lds = lds_of(true);
+    // sub-group mapping (S < 3): the shared-gradient sums always go through LDS, so that a block leaves ONE partial vector (the
+    // fixed-order sum of its sub-groups') whether it walks one group or many - 4x fewer vectors for k_reduce_partials
+    else if (nsg > 1) p.persist = 1, p.lds = lds_of(true);
   }
-  p.nparts = p.blocks * nsg;
+  p.nparts = p.persist ? p.blocks : p.blocks * nsg;
   return p;
 }
 
@@ -830,12 +861,17 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   float *red = red2 + (size_t)RCH * a.n_shared;
   D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256, RCH), dim3(256), 0, stream,
               (const float *)grads->partials, pl.nparts, a.n_shared, red2);
-  D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256, 1), dim3(256), 0, stream,
-              (const float *)red2, RCH, a.n_shared, red);
   int fin = dims->G > 0 ? dims->K * dims->T * 9 : 0;
   if (fin < dims->S * 12) fin = dims->S * 12;
   if (fin < 16) fin = 16;
-  D4GS_LAUNCH("k_finish", k_finish, dim3((fin + 255) / 256), dim3(256), 0, stream, a, (const float *)red);
+  const size_t fin_lds = sizeof(float) * (size_t)a.n_shared;
+  if (fin_lds <= 64 * 1024) {  // second reduction pass inside k_finish (every block redoes it: RCH x n_shared loads, L2-resident)
+    D4GS_LAUNCH("k_finish", k_finish, dim3((fin + 255) / 256), dim3(256), fin_lds, stream, a, (const float *)red2, RCH);
+    return d4gs_check_launch("k_finish");
+  }
+  D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256, 1), dim3(256), 0, stream,
+              (const float *)red2, RCH, a.n_shared, red);
+  D4GS_LAUNCH("k_finish", k_finish, dim3((fin + 255) / 256), dim3(256), 0, stream, a, (const float *)red, 0);
   return d4gs_check_launch("k_finish");
 }
 

@@ -4,9 +4,14 @@
 // v_means2d / v_conics / v_colors / v_opacities) and the autograd of the RGB+ED division.
 // Reference: the backward of flow3d/scene_model.py:360-373, driven by flow3d/trainer.py:231.
 //
-// CDNA4 mapping
-//   * one wave64 per 16x16 tile, 2x2 pixels per lane (same mapping as the forward): each splat's contribution
-//     is first summed over the lane's 4 pixels in registers, then over the wave with 6 DPP adds per value.
+// CDNA4 mapping (k_raster_bwd_q, "variant B", the only composite backward in libd4gs.so; details at raster_bwd_q_body)
+//   * one 256-lane workgroup per 16x16 tile (few-tile launches: per (tile, depth segment)), its 4 waves own the 4 8x8 quadrants,
+//     1 pixel / lane; 64-splat batches are staged back to front once per tile; a wave replays a staged splat only if its tight
+//     alpha >= 1/255 box touches the quadrant and it lies at or before the quadrant's last contributor (ballot);
+//   * each replayed splat's row (6 moments + channels) is reduced over the wave's 64 lanes with v_permlane32/16_swap + DPP adds
+//     into the wave's own LDS slab; the 4 slabs are added in fixed order at write-out.  60 VGPRs / 15.4 KB LDS for D <= 5 ->
+//     8 waves per SIMD.  (Variant A - one wave per tile, 2x2 pixels per lane - and variant C - MFMA reductions - live in
+//     variants/raster_bwd_variants.inc, tests' A/B library only.)
 //   * NO float atomics: the wave's reduced gradient row (x, y, conic a/b/c, opacity, colours, depth) is written to
 //     a per-INTERSECTION buffer at the splat's emission index.  Rows of one Gaussian instance are contiguous there,
 //     so k_gather sums them with plain loads in a fixed order -> bitwise reproducible gradients, and no
@@ -38,7 +43,21 @@ struct RasterBwdArgs {
   const int64_t *n_dev;  // device {total, longest list}; the lists were sized for (cap, max_hint) - see binning.hip
   int64_t cap, max_hint;
   const float *seg_state;  // SEG instantiations: the forward's per-pixel state at the depth-segment boundaries (common.h)
+#ifdef D4GS_TRACE  // A/B builds only (scripts/trace_wgs.py): per-workgroup {start, end} wall clock, hardware id, list entries
+  unsigned long long *trace;
+#endif
 };
+#ifdef D4GS_TRACE
+#define D4GS_TRACE_BEGIN const unsigned long long _t0 = wall_clock64();
+#define D4GS_TRACE_END(n_)                                                                                     \
+  if (a.trace && threadIdx.x == 0) {                                                                           \
+    unsigned long long *tr = a.trace + (size_t)blockIdx.x * 4;                                                 \
+    tr[0] = _t0, tr[1] = wall_clock64(), tr[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32), tr[3] = (unsigned long long)(n_); \
+  }
+#else
+#define D4GS_TRACE_BEGIN
+#define D4GS_TRACE_END(n_)
+#endif
 
 // The forward stage skips its work when the device-side intersection count exceeds what the caller sized the lists for
 // (optimistic / deferred sizing, engine.py).  The backward must not touch those lists either: tile_offsets are computed from
@@ -62,7 +81,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Variant B (default): one 256-lane workgroup per tile = 4 waves, each wave owns an 8x8 QUADRANT (1 pixel / lane),
-// batches of 128 splats staged back-to-front once per tile together with their tight alpha >= 1/255 boxes.  Every
+// batches of 64 splats staged back-to-front once per tile together with their tight alpha >= 1/255 boxes.  Every
 // wave ballots which staged splats (a) touch its quadrant and (b) lie at or before the quadrant's last contributor,
 // and replays only those.  Each wave reduces its row over its 64 lanes (permlane swaps) into its own LDS slab; the
 // four slabs are added in fixed order when the batch is written out - still no atomics, still deterministic.
@@ -106,12 +125,18 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
   __shared__ float sgrad[4 * NB * RP];
   __shared__ int shi[4];
 
+  D4GS_TRACE_BEGIN
   if (lists_overflowed(a.n_dev, a.cap, a.max_hint)) return;
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
-  const int lb = xcd_remap_b(blockIdx.x, SEG ? n_tiles * D4GS_SEG_MAX : n_tiles);  // (a tile's segments stay on one XCD)
-  const int t = SEG ? lb / D4GS_SEG_MAX : lb, seg = SEG ? lb - t * D4GS_SEG_MAX : 0;
-  if (t >= n_tiles) return;
+  // SEG: block b runs on XCD b % 8; inside an XCD the order is SEGMENT-major over the XCD's tiles (all first segments, then
+  // all second ones, ...): a tile's segments share its XCD's L2, and the slots past a list's end - workgroups that exit at
+  // once - come last.  (Tile-major order interleaves working and empty workgroups with a period the dispatcher's round robin
+  // over shader engines / CUs aliases with: measured, half of the CUs received only empty workgroups.)
+  const int per_xcd = (n_tiles + 7) >> 3, bi = blockIdx.x >> 3;
+  const int seg = SEG ? bi / per_xcd : 0;
+  const int t = SEG ? (blockIdx.x & 7) * per_xcd + (bi - seg * per_xcd) : xcd_remap_b(blockIdx.x, n_tiles);
+  if (t >= n_tiles || seg >= D4GS_SEG_MAX) return;
   int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
   if constexpr (SEG) {  // from here on [start, end) is this workgroup's segment of the list
     const int sl = d4gs_seg_len(end - start);
@@ -344,6 +369,7 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
       if (a.sparse) a.live[emit] = 1;
     }
   }
+  D4GS_TRACE_END(end - start)
 }
 // Two entry points over one body: the narrow instantiations (D <= 5) are asked for 8 waves per SIMD (the hint changes the
 // scheduler's register budget); the wide ones keep the compiler's default - the hint cannot be met there and only perturbs them.
@@ -456,8 +482,8 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
       // (row order = instance-major, ascending k), (3) the wave fetches those rows 64 at a time - one row per lane, all
       // loads in flight together - into the LDS stage, (4) every lane adds ITS rows from the stage: their positions are the
       // live-row counts in front of its first / behind its last row (group prefix + popcount of the group's flags).  Same
-      // k order as the streaming path -> the same bits.  Super-chunks that are >= 1 / 4 live, or hold more live rows than
-      // the stage, take the streaming path below.
+      // k order as the streaming path -> the same bits.  From the first super-chunk that is more than 1 / 2 live on (`L * 2 >
+      // se - sb` below) the rest of the span takes the streaming path.
       uint32_t *myflag = sflag + wv * (GATHER_SC / 4);
       uint16_t *mygrp = sgrp + wv * (GATHER_SC / 16 + 1);
       uint16_t *mylist = slist + wv * GATHER_SC;
@@ -635,9 +661,11 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   for (int c = 0; c < DP; c++) a.v_ctab[(size_t)g * DP + c] = c < D ? vc[c < D ? c : 0] : 0.f;
 }
 
-// Sparse rows pay when most rows are dead, which goes with large footprints: the rows per (sub-sample, Gaussian) instance
-// the lists were sized for is what the host knows without a round trip.  Measured: 1.8 rows per
-// instance -> dense is 3 % faster; 7.4 -> sparse is 13 % faster.  D4gsRasterGrads.row_mode overrides.
+// Row mode when the caller leaves it to the library (D4gsRasterGrads.row_mode == D4GS_ROWS_AUTO).  deblur4dgs_amd/engine.py does
+// NOT: since round 3 it passes DENSE / SPARSE from the live-row fraction the forward composite sampled on the previous render of
+// the shape (engine.row_mode_for; D4gsProjOut.n_isect[2..3]).  This fallback only knows the rows per (sub-sample, Gaussian)
+// instance the lists were sized for - large footprints go with dead rows: measured 1.8 rows per instance -> dense is 3 %
+// faster; 7.4 -> sparse is 13 % faster.
 static bool choose_sparse(int row_mode, int64_t n_isect, int64_t n_inst) {
   if (row_mode == D4GS_ROWS_DENSE) return false;
   if (row_mode == D4GS_ROWS_SPARSE) return true;
@@ -679,7 +707,7 @@ int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, 
       }
     }
     if (n_isect > 0 && a.seg_state) {
-      const int sblocks = ((n_tiles * D4GS_SEG_MAX + 7) / 8) * 8;
+      const int sblocks = ((n_tiles + 7) / 8) * 8 * D4GS_SEG_MAX;
       if constexpr (D <= 5) D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_qs8<D, DEPTH>), dim3(sblocks), dim3(256), 0, stream, a);
       else D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_qs<D, DEPTH>), dim3(sblocks), dim3(256), 0, stream, a);
     } else if (n_isect > 0) {
@@ -711,6 +739,9 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.v_out = g->v_render_colors, a.v_alphas = g->v_render_alphas, a.isect_grad = g->isect_grad, a.live = g->isect_live;
   a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
   a.seg_state = d4gs_seg_on(dims, isect, r) ? r->seg_state : nullptr;
+#ifdef D4GS_TRACE
+  a.trace = getenv("D4GS_TRACE_PTR") ? (unsigned long long *)strtoull(getenv("D4GS_TRACE_PTR"), nullptr, 0) : nullptr;
+#endif
   GatherArgs ga;
   ga.n_dev = proj->n_isect, ga.cap = isect->n_isect, ga.max_hint = isect->max_tile_count;
   ga.rows = isect->n_isect > 0 ? isect->n_isect : 1;

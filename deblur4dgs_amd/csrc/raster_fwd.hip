@@ -3,12 +3,17 @@
 // Replaces gsplat rasterize_to_pixels_fwd<CDIM> (+ the Python-side expected-depth division of
 // rasterization(render_mode="RGB+ED")); reference call site flow3d/scene_model.py:360-373.
 //
-// CDNA4 mapping: ONE wave64 per 16x16 tile, each lane owns a 2x2 pixel quad (4 pixels / lane):
-//   * the per-splat record is read once from LDS (broadcast ds_read_b128) and reused for 4 pixels, so the
-//     composite is VALU-bound, not LDS-bound, and per-splat loop overhead is amortised 4x;
-//   * a single-wave workgroup needs no cross-wave barrier: batches of 64 splats are staged by the wave's own
-//     64 lanes (one coalesced id load + one 32-B geom gather + the colour row per lane);
-//   * early exit is one ballot per 16 splats.
+// CDNA4 mapping (k_raster_fwd_r, "variant D", the only forward in libd4gs.so): ONE 256-lane workgroup per 16x16 tile, its 4
+// waves own the 4 8x8 QUADRANTS, and each 16-lane ROW of a wave is an independent 4x4-pixel rasterizer (1 pixel / lane):
+//   * batches of 256 (128 for wide colour records) splats are staged once per tile in LDS - geometry, conic, colours and the
+//     splat's tight alpha >= 1/255 box (4 x f16, tile-local) - by the workgroup's lanes: one coalesced id load + one 32-B
+//     geom gather + the colour row per lane;
+//   * per batch every wave compacts one list of staged indices PER ROW (ballot + mbcnt over the boxes that touch the row's 4x4
+//     block, order preserved) and its four rows walk their own lists in lock-step: one iteration composites up to four
+//     different splats, the loop body is branch-free, saturation is checked once per 16 iterations;
+//   * 54 VGPRs / 18.7 KB LDS for D <= 4 -> 8 waves per SIMD.
+// The earlier mappings (A: one wave per tile with 2x2 pixels per lane; B: quadrant waves without row lists) live in
+// variants/raster_fwd_variants.inc and are compiled only into the tests' A/B library.
 // Block -> tile mapping is XCD-aware: consecutive logical tiles (same sub-sample, neighbouring tiles, shared
 // splats) land on the same XCD so the gathered records hit that XCD's L2.
 #include <stdlib.h>
@@ -88,7 +93,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int DV = DP / 4;
-  constexpr int FB = DV > 2 ? 128 : 256;  // splats per batch (indices fit one byte); wide colour records: smaller
+  constexpr int FB = (DV > 2 || (SEG && D4GS_SEG_UNIT < 256)) ? 128 : 256;  // splats per batch (indices fit one byte); wide colour records: smaller
                                            // batches keep 4+ workgroups per CU (measured 17-ch: 0.45 -> 0.42 ms)
   __shared__ float4 sg0[FB];
   __shared__ float4 sg1[FB];
@@ -313,7 +318,7 @@ int64_t d4gs_seg_state_elems(const D4gsDims *d) {
   return n_tiles * D4GS_SEG_MAX * (1 + nch) * 256;
 }
 bool d4gs_seg_on(const D4gsDims *d, const D4gsIsect *isect, const D4gsRaster *r) {
-  static const char *env = getenv("D4GS_SEG");  // "0": never, "1": whenever the buffer is there (tests); default: see below
+  const char *env = getenv("D4GS_SEG");  // (read per call: tests toggle it) "0": never, "1": whenever the buffer is there (tests); default: see below
   if (!r->seg_state || d4gs_seg_state_elems(d) == 0 || (env && env[0] == '0')) return false;
 #ifdef D4GS_VARIANTS  // the environment-selected reference variants neither write nor read the boundary states
   if (getenv("D4GS_FWD_WAVE_PER_TILE") || getenv("D4GS_FWD_QUADS") || getenv("D4GS_BWD_WAVE_PER_TILE") || getenv("D4GS_BWD_MFMA"))

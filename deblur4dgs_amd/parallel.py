@@ -295,9 +295,14 @@ class ShardedExposure:
         self.reducer = None
         self.deferred_size_check = False  # True: no render waits for its list sizes on the host (engine.RenderCfg) - needed
         #                                   to capture the step, collectives included, in a HIP graph
+        self.render = None  # None: deblur4dgs_amd.exposure.render_exposure.  bench.py --dry-run puts a synthetic CPU image
+        #                     function here to run the N > 1 control flow (collectives, timing, agreement) on gloo without a GPU
 
     def step(self, leaves: dict, Kmat, W: int, H: int, background, wimg, wacc):
-        from .exposure import render_exposure
+        if self.render is not None:
+            render_exposure = self.render
+        else:
+            from .exposure import render_exposure
 
         S = leaves["times"].shape[0]
         if self.reducer is None:

@@ -231,3 +231,32 @@ def test_owned_subsamples_partition():
         for world in (1, 2, 4, 8):
             allv = sorted(s for r in range(world) for s in owned_subsamples(S, world, r))
             assert allv == list(range(S))
+
+
+@pytest.mark.parametrize("flags,expect_launch", [(["--no-graph"], None), ([], "graph capture failed")])
+def test_bench_n_gt_1_control_flow_runs_on_gloo(flags, expect_launch):
+    """the first multi-GPU SCALE run must not also be the first run of bench.py's N > 1 code.  `--dry-run` drives
+    exactly that code on CPU tensors over gloo, launched the way the driver launches it (torch.distributed.run, one process per
+    "GPU"): process group, the exposure-sharded step with its blend collectives and the armed gradient all-reduce, the eager path
+    (`--no-graph`) and the default path in which rank 0 fails to capture its HIP graph and the cross-rank MIN agreement must send
+    BOTH ranks to the eager step, max-over-ranks timing, the secondary view-sharded measurement - and ONE JSON line on stdout."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--dry-run", *flags]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]  # (gloo's own connection banner)
+    assert len(lines) == 1, r.stdout  # the contract: ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["data"].startswith("dry-run") and d["ms_per_step"] > 0
+    assert d["views_weak_scaling"]["value"] > 0 and d["views_weak_scaling"]["scaling"] == "weak"
+    if expect_launch is None:
+        assert "launch" not in d["config"]
+    else:
+        assert expect_launch in d["config"]["launch"]  # rank 0 could not capture -> every rank timed the eager step
