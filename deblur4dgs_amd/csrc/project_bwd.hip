@@ -865,7 +865,10 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   if (fin < dims->S * 12) fin = dims->S * 12;
   if (fin < 16) fin = 16;
   const size_t fin_lds = sizeof(float) * (size_t)a.n_shared;
-  if (fin_lds <= 64 * 1024) {  // second reduction pass inside k_finish (every block redoes it: RCH x n_shared loads, L2-resident)
+  // second reduction pass inside k_finish - for SHORT shared vectors only (one or two sub-samples: a rank of a sharded frame):
+  // every block of k_finish redoes it (RCH x n_shared loads), which costs more than the launch it saves from ~256 floats on
+  // (measured: cfg2 S = 8, 540 floats: 13 -> 19 us; refdefault, 2 124 floats: 13 -> 60 us; S = 1, 78 floats: 24 -> 16 us)
+  if (a.n_shared <= 160) {
     D4GS_LAUNCH("k_finish", k_finish, dim3((fin + 255) / 256), dim3(256), fin_lds, stream, a, (const float *)red2, RCH);
     return d4gs_check_launch("k_finish");
   }

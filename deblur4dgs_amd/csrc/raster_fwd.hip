@@ -38,7 +38,17 @@ struct RasterFwdArgs {
                    // sized for (see binning.hip); [2], [3]: this kernel's live-row sample
   int64_t cap, max_hint;
   float *seg_state;  // SEG instantiations: [tiles][D4GS_SEG_MAX][1 + NCH][256] boundary states (common.h "depth segments")
+#ifdef D4GS_TRACE  // A/B builds only (scripts/trace_wgs.py --fwd): per-workgroup wall clock {start, end}, hardware id, list entries,
+  unsigned long long *trace;  // and the time spent in the staging / list-building / compositing phases of its batches
+#endif
 };
+#ifdef D4GS_TRACE
+#define D4GS_TCLK(v_) const unsigned long long v_ = wall_clock64();
+#define D4GS_TADD(acc_, a_, b_) acc_ += (b_) - (a_);
+#else
+#define D4GS_TCLK(v_)
+#define D4GS_TADD(acc_, a_, b_)
+#endif
 
 __device__ __forceinline__ int xcd_remap(int b, int n_blocks) {
   const int per = (n_blocks + 7) >> 3;
@@ -101,6 +111,10 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   __shared__ float4 scol[FB * DV];
   __shared__ unsigned char slist[4 * 4 * FB];  // [wave][row][position]
 
+  D4GS_TCLK(_t0)
+#ifdef D4GS_TRACE
+  unsigned long long _ts = 0, _tl = 0, _tc = 0;
+#endif
   if (a.n_dev && (a.n_dev[0] > a.cap || (a.max_hint > 0 && a.n_dev[1] > a.max_hint))) return;
   const int n_tiles_s = a.tw * a.th;
   const int n_tiles = a.S * n_tiles_s;
@@ -146,6 +160,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   };
   for (int b = start; b < end; b += FB) {
     if (__syncthreads_and(done)) break;  // also orders the previous batch's LDS reads before restaging
+    D4GS_TCLK(_ta)
     const int idx = b + tid;
     if (tid < FB && idx < end) {
       const int gid = a.sorted_gid[idx];
@@ -167,6 +182,8 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       for (int v = 0; v < DV; v++) scol[tid * DV + v] = cp[v];
     }
     __syncthreads();
+    D4GS_TCLK(_tb)
+    D4GS_TADD(_ts, _ta, _tb)
     const int nb = min(FB, end - b);
     // ---- per-row lists of this wave's quadrant ----
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // wave-uniform list lengths
@@ -189,6 +206,8 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       c0 += __popcll(m0), c1 += __popcll(m1), c2 += __popcll(m2), c3 += __popcll(m3);
     }
     __builtin_amdgcn_wave_barrier();
+    D4GS_TCLK(_tc0)
+    D4GS_TADD(_tl, _tb, _tc0)
     const int cnt = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
     const int imax = max(max(c0, c1), max(c2, c3));
     int lastj = -1;
@@ -226,6 +245,8 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     }
     last = lastj >= 0 ? b + lastj : last;  // list index of the batch's last contributor, formed once per batch
     has_last = has_last || lastj >= 0;
+    D4GS_TCLK(_tc1)
+    D4GS_TADD(_tc, _tc0, _tc1)
     if constexpr (SEG) {
       const int e = b + FB - start;  // entries composited so far (a boundary is never the end of the list: slot 0 holds that)
       if (e < end - start && e % seglen == 0) seg_store(e / seglen);
@@ -260,6 +281,13 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     for (int c = 0; c < D; c++) o[c] = acc[c] + (a.background ? T * a.background[c] : 0.f);
     if (DEPTH) o[D] = a.ed ? acc[D] / fmaxf(al, 1e-10f) : acc[D];
   }
+#ifdef D4GS_TRACE
+  if (a.trace && tid == 0) {
+    unsigned long long *tr = a.trace + (size_t)blockIdx.x * 8;
+    tr[0] = _t0, tr[1] = wall_clock64(), tr[3] = (unsigned long long)(end - start), tr[4] = _ts, tr[5] = _tl, tr[6] = _tc;
+    tr[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+  }
+#endif
 }
 // Two entry points over one body: the narrow instantiations (D <= 4) are asked for 8 waves per SIMD (the hint changes the
 // scheduler's register budget); the wide ones keep the compiler's default - the hint cannot be met there and only perturbs them.
@@ -342,6 +370,9 @@ int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   a.seg_state = d4gs_seg_on(dims, isect, r) ? r->seg_state : nullptr;
+#ifdef D4GS_TRACE
+  a.trace = getenv("D4GS_TRACE_FWD_PTR") ? (unsigned long long *)strtoull(getenv("D4GS_TRACE_FWD_PTR"), nullptr, 0) : nullptr;
+#endif
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
 #define D4GS_CASE(DD)                                                   \
   case DD:                                                              \

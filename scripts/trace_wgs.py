@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--share", type=int, default=8)
 ap.add_argument("--seg", default=None)
+ap.add_argument("--fwd", action="store_true", help="trace the forward composite (8 words per workgroup incl. phase times)")
 a = ap.parse_args()
 if a.seg is not None:
     os.environ["D4GS_SEG"] = a.seg
@@ -22,7 +23,8 @@ times = leaves["times"][::a.share].detach().clone().requires_grad_()
 RTs = leaves["RTs"][::a.share].detach().clone().requires_grad_()
 bg = torch.ones(3, device=dev)
 NB = 1 << 16
-trace = torch.zeros(NB * 4, dtype=torch.int64, device=dev)
+RW = 8 if a.fwd else 4
+trace = torch.zeros(NB * RW, dtype=torch.int64, device=dev)
 
 
 def step():
@@ -34,11 +36,11 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-os.environ["D4GS_TRACE_PTR"] = hex(trace.data_ptr())
+os.environ["D4GS_TRACE_FWD_PTR" if a.fwd else "D4GS_TRACE_PTR"] = hex(trace.data_ptr())
 trace.zero_()
 step()
 torch.cuda.synchronize()
-t = trace.view(NB, 4).cpu()
+t = trace.view(NB, RW).cpu()
 used = t[:, 1] > 0
 t = t[used]
 t0 = int(t[:, 0].min())
@@ -61,6 +63,10 @@ per_cu = torch.zeros(int(key.max()) + 1)
 per_cu.index_add_(0, key[act], life[act].float())
 busy = per_cu[per_cu > 0]
 print(f"  {len(busy)} distinct (xcc, se, sh, cu) ids; summed WG lifetime per id (us): min {float(busy.min()):.0f} p50 {float(busy.median()):.0f} max {float(busy.max()):.0f}")
+if a.fwd:
+    for nm, col in (("staging (global loads -> LDS -> barrier)", 4), ("row-list building", 5), ("compositing", 6)):
+        v = t[:, col].double()[act] / 100.0
+        print(f"  per-WG time in {nm}: p10 {float(v.quantile(0.1)):.1f} p50 {float(v.median()):.1f} p90 {float(v.quantile(0.9)):.1f} us")
 for lo in range(0, int(en.max()) + 20, 20):
     alive = int(((st <= lo) & (en > lo) & act).sum())
     print(f"    t = {lo:4d} us: {alive} working WGs alive")
