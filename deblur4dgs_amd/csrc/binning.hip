@@ -46,7 +46,8 @@ __device__ __forceinline__ bool over_capacity(const int64_t *n_dev, int64_t cap,
 // Which slot a key lands in is irrelevant (k_tile_sort orders the list by depth, then emission index), so nothing
 // has to be carried from the counting pass, splats of any footprint take the same path, and the 8-byte key stores
 // of a block fall into short contiguous runs.  Tile grids too big for the LDS histogram use global cursors.
-constexpr int EMIT_THREADS = 1024, EMIT_PER_THREAD = 4;
+constexpr int EMIT_THREADS = 1024;
+template <int EMIT_PER_THREAD>  // = d4gs_chunk_per_thread(dims), like k_count_tiles
 __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
   extern __shared__ int bins[];  // [tiles]
   if (over_capacity(a.n_dev, a.cap, a.max_hint)) return;
@@ -409,15 +410,19 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
   e.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   e.n_dev = proj->n_isect, e.cap = isect->n_isect, e.max_hint = isect->max_tile_count;
-  const int per_block = EMIT_THREADS * EMIT_PER_THREAD;
+  const int pt = d4gs_chunk_per_thread(dims), per_block = EMIT_THREADS * pt;
   if (e.nchunks && e.nchunks != (dims->N + per_block - 1) / per_block) {  // k_count_tiles' chunks must be this kernel's
     d4gs_set_error("internal: fused scan chunking mismatch (%d vs %d)", e.nchunks, (dims->N + per_block - 1) / per_block);
     return D4GS_EINVAL;
   }
   const size_t bins_bytes = sizeof(int) * (size_t)e.tw * e.th;
   e.use_lds = bins_bytes <= 64 * 1024;
-  D4GS_LAUNCH("k_emit", k_emit, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS),
-              e.use_lds ? bins_bytes : 0, stream, e);
+  if (pt == 1)
+    D4GS_LAUNCH("k_emit", k_emit<1>, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS),
+                e.use_lds ? bins_bytes : 0, stream, e);
+  else
+    D4GS_LAUNCH("k_emit", k_emit<4>, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS),
+                e.use_lds ? bins_bytes : 0, stream, e);
   int rc = d4gs_check_launch("k_emit");
   if (rc) return rc;
   const int n_tiles = dims->S * e.tw * e.th;

@@ -326,6 +326,9 @@ int64_t d4gs_seg_state_elems(const D4gsDims *d);
 // do the composite kernels of this launch use segments?  (the forward writes the boundary states, the backward replays by segment)
 bool d4gs_seg_on(const D4gsDims *d, const D4gsIsect *isect, const D4gsRaster *r);
 
+// Instances per lane of the 1024-lane blocks of k_count_tiles / k_emit (their chunks must agree): 4 - or 1 when 4 would leave
+// fewer blocks than CUs (one or two sub-samples of a few 100 k Gaussians: S = 1, N = 300 k gave 74 blocks for 256 CUs).
+int d4gs_chunk_per_thread(const D4gsDims *d);
 // > 0: the fused scan is in effect for this configuration and this is its chunk count per sub-sample (project_fwd.hip)
 int d4gs_fused_scan_chunks(const D4gsDims *d);
 

@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(POSE_GPB * POSE_SLOTS) k_poses_fwd(const Poses
 // every non-empty bin to the global counter with one atomic: ~13x fewer global atomics.  (k_emit later repeats the
 // same histogram to hand out the slots, see binning.hip.)
 // ---------------------------------------------------------------------------------------------------
-constexpr int COUNT_THREADS = 1024, COUNT_PER_THREAD = 4;
+constexpr int COUNT_THREADS = 1024;
+template <int COUNT_PER_THREAD>
 __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__restrict__ tile_rects,
                                                               const int *__restrict__ tiles_touched, int N, int S, int tw,
                                                               int th, int *__restrict__ tile_counts, int *__restrict__ chunk_sums) {
@@ -456,8 +457,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const int *in, cons
 
 }  // namespace
 
-extern "C" size_t d4gs_scan_ws_elems(int64_t n_instances) {
-  return (size_t)((n_instances + SCAN_TILE - 1) / SCAN_TILE) + 16;
+extern "C" size_t d4gs_scan_ws_elems(int64_t n_instances) {  // (block sums of the two-pass scan / chunk sums of the fused one)
+  return (size_t)((n_instances + COUNT_THREADS - 1) / COUNT_THREADS) + 64;
+}
+
+int d4gs_chunk_per_thread(const D4gsDims *d) {
+  const int64_t blocks4 = (((int64_t)d->N + 4 * COUNT_THREADS - 1) / (4 * COUNT_THREADS)) * d->S;
+  return blocks4 < 256 ? 1 : 4;
 }
 
 // Fused scan of the per-instance intersection counts (small tile grids, i.e. every BASELINE config): k_count_tiles also
@@ -469,7 +475,7 @@ int d4gs_fused_scan_chunks(const D4gsDims *d) {
   static const bool off = getenv("D4GS_NO_FUSED_SCAN") != nullptr;  // A/B hook
   const int tw = (d->width + D4GS_TILE - 1) / D4GS_TILE, th = (d->height + D4GS_TILE - 1) / D4GS_TILE;
   if (off || force_in_kernel || d->N <= 0 || sizeof(int) * (size_t)tw * th > 64 * 1024) return 0;
-  const int per_block = COUNT_THREADS * COUNT_PER_THREAD;
+  const int per_block = COUNT_THREADS * d4gs_chunk_per_thread(d);
   const int64_t nchunks = (d->N + per_block - 1) / per_block;
   if ((size_t)(nchunks * d->S) + 1 > d4gs_scan_ws_elems((int64_t)d->S * d->N)) return 0;  // tiny N, many sub-samples
   return (int)nchunks;
@@ -524,11 +530,16 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   int rc = d4gs_check_launch("k_project_fwd");
   if (rc) return rc;
   if (a.count_apart) {
-    const int per_block = COUNT_THREADS * COUNT_PER_THREAD;
+    const int pt = d4gs_chunk_per_thread(dims), per_block = COUNT_THREADS * pt;
     const int cblocks = ((dims->N + per_block - 1) / per_block) * dims->S;
-    D4GS_LAUNCH("k_count_tiles", k_count_tiles, dim3(cblocks), dim3(COUNT_THREADS), hist_bytes, stream,
-                (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th,
-                out->tile_counts, fused_chunks ? out->scan_ws : (int *)nullptr);
+    if (pt == 1)
+      D4GS_LAUNCH("k_count_tiles", k_count_tiles<1>, dim3(cblocks), dim3(COUNT_THREADS), hist_bytes, stream,
+                  (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th,
+                  out->tile_counts, fused_chunks ? out->scan_ws : (int *)nullptr);
+    else
+      D4GS_LAUNCH("k_count_tiles", k_count_tiles<4>, dim3(cblocks), dim3(COUNT_THREADS), hist_bytes, stream,
+                  (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th,
+                  out->tile_counts, fused_chunks ? out->scan_ws : (int *)nullptr);
     rc = d4gs_check_launch("k_count_tiles");
     if (rc) return rc;
   }

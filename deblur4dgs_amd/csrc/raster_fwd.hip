@@ -113,7 +113,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 
   D4GS_TCLK(_t0)
 #ifdef D4GS_TRACE
-  unsigned long long _ts = 0, _tl = 0, _tc = 0;
+  unsigned long long _ts = 0, _tl = 0, _tc = 0, _ti = 0;
 #endif
   if (a.n_dev && (a.n_dev[0] > a.cap || (a.max_hint > 0 && a.n_dev[1] > a.max_hint))) return;
   const int n_tiles_s = a.tw * a.th;
@@ -247,6 +247,9 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     has_last = has_last || lastj >= 0;
     D4GS_TCLK(_tc1)
     D4GS_TADD(_tc, _tc0, _tc1)
+#ifdef D4GS_TRACE
+    _ti += (unsigned long long)imax;
+#endif
     if constexpr (SEG) {
       const int e = b + FB - start;  // entries composited so far (a boundary is never the end of the list: slot 0 holds that)
       if (e < end - start && e % seglen == 0) seg_store(e / seglen);
@@ -284,7 +287,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 #ifdef D4GS_TRACE
   if (a.trace && tid == 0) {
     unsigned long long *tr = a.trace + (size_t)blockIdx.x * 8;
-    tr[0] = _t0, tr[1] = wall_clock64(), tr[3] = (unsigned long long)(end - start), tr[4] = _ts, tr[5] = _tl, tr[6] = _tc;
+    tr[0] = _t0, tr[1] = wall_clock64(), tr[3] = (unsigned long long)(end - start), tr[4] = _ts, tr[5] = _tl, tr[6] = _tc, tr[7] = _ti;
     tr[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
   }
 #endif

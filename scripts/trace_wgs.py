@@ -67,6 +67,10 @@ if a.fwd:
     for nm, col in (("staging (global loads -> LDS -> barrier)", 4), ("row-list building", 5), ("compositing", 6)):
         v = t[:, col].double()[act] / 100.0
         print(f"  per-WG time in {nm}: p10 {float(v.quantile(0.1)):.1f} p50 {float(v.median()):.1f} p90 {float(v.quantile(0.9)):.1f} us")
+if a.fwd:
+    it = t[:, 7].double()[act]
+    comp = t[:, 6].double()[act] / 100.0
+    print(f"  walk iterations of wave 0 per WG: p10 {int(it.quantile(0.1))} p50 {int(it.median())} p90 {int(it.quantile(0.9))}; compositing ns per iteration: p50 {float((1e3 * comp / it.clamp(min=1)).median()):.0f}")
 for lo in range(0, int(en.max()) + 20, 20):
     alive = int(((st <= lo) & (en > lo) & act).sum())
     print(f"    t = {lo:4d} us: {alive} working WGs alive")
