@@ -658,8 +658,9 @@ def main():
                 sq_doc = _load_json("profiles", f"{cur.get('round', 'r03')}_pmc_sq_cfg2.json")
                 sq_ok = _counters_current(sq_doc) and name == "cfg2" and channels == 3 and args.scale_mul == 1.0
                 sq = sq_doc.get(dom) if sq_ok else None
-                lanes = _load_json("profiles", "r02_lane_stats_cfg2.json") if sq_ok else None  # (a property of the scene and
-                #                                       of the quadrant mapping, both unchanged since round 2)
+                lanes = _load_json("profiles", f"{cur.get('round', 'r03')}_lane_stats_cfg2.json") if sq_ok else None
+                if not _counters_current(lanes):  # scripts/pair_stats.py of the same profiling round, same library
+                    lanes = None
                 if not sq_ok and name == "cfg2" and channels == 3:
                     roof["counters_note"] = ("profiles/ holds PMC counters of another build of libd4gs.so (sha256 mismatch): "
                                              "`traffic` / `hardware` omitted rather than quoted stale; scripts/profile_round.sh "
@@ -668,7 +669,7 @@ def main():
                     clk_cycles = sq["GRBM_GUI_ACTIVE"] / N_XCD  # the counter is summed over the 8 XCDs
                     insts = sq["SQ_INSTS_VALU"]
                     hw = {"source": f"profiles/{cur.get('round', 'r03')}_pmc_sq_cfg2.json (rocprofv3 --pmc, own pass, same libd4gs.so by "
-                                    "sha256), profiles/r02_lane_stats_cfg2.json",
+                                    f"sha256), profiles/{cur.get('round', 'r03')}_lane_stats_cfg2.json (scripts/pair_stats.py on the benched scene, same library)",
                           "valu_wave_insts_per_launch": insts, "kernel_cycles": clk_cycles,
                           "cycles_per_valu_inst_per_simd": clk_cycles * N_SIMD / insts,
                           "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] / (clk_cycles * N_CU),
@@ -679,6 +680,8 @@ def main():
                         replayed_lanes = lanes["bwd_quadrant_replays"] * 64.0 * (isect_replayed / max(lanes["n_isect"], 1))
                         nec = vp * FLOPS_PER_PAIR_BWD + (replayed_lanes - vp) * FLOPS_INVALID_PAIR
                         hw.update(active_lane_fraction=af, replays_with_no_valid_lane=lanes["bwd_replays_with_no_valid_lane"],
+                                  alpha_passing_pairs=lanes["bwd_valid_pairs"], nominal_pairs=lanes.get("bwd_nominal_pairs"),
+                                  quadrant_replays=lanes["bwd_quadrant_replays"],
                                   necessary_flops_per_launch=nec, necessary_tflops=nec / t_k / 1e12,
                                   frac_necessary=nec / t_k / 1e12 / F32_PEAK_TFLOPS,
                                   necessary_note="90 flop only for lanes that pass the alpha test, 12 for the other lanes "

@@ -102,7 +102,7 @@ GEOM_STRIDE = 8
 EXPORTS = (
     "d4gs_version", "d4gs_copy_counts", "d4gs_last_error", "d4gs_scan_ws_elems", "d4gs_bwd_partials_elems", "d4gs_project_fwd",
     "d4gs_bin_sort", "d4gs_raster_fwd", "d4gs_raster_bwd", "d4gs_project_bwd", "d4gs_blend_fwd", "d4gs_blend_bwd",
-    "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_poses_fwd", "d4gs_poses_bwd", "d4gs_forward", "d4gs_backward", "d4gs_forward_cpu", "d4gs_backward_cpu", "d4gs_frame_workspace_bytes", "d4gs_blend_shard_partial_fwd", "d4gs_blend_shard_finish_fwd",
+    "d4gs_points_fwd", "d4gs_points_bwd", "d4gs_poses_fwd", "d4gs_poses_bwd", "d4gs_forward", "d4gs_backward", "d4gs_forward_cpu", "d4gs_backward_cpu", "d4gs_frame_workspace_bytes", "d4gs_frame_workspace_bytes_fwd", "d4gs_blend_shard_partial_fwd", "d4gs_blend_shard_finish_fwd",
     "d4gs_blend_shard_winner", "d4gs_blend_shard_bwd", "d4gs_control_stats", "d4gs_control_plan", "d4gs_gather_rows", "d4gs_camera_path_fwd", "d4gs_camera_path_bwd",
     "d4gs_pose_encode", "d4gs_pose_encode_bwd", "d4gs_move_model_fwd", "d4gs_move_model_bwd",
     "d4gs_photometric_blocks", "d4gs_photometric_fwd", "d4gs_photometric_bwd", "d4gs_query_sizes", "d4gs_profile_enable", "d4gs_profile_collect", "d4gs_measure_peaks",
@@ -147,6 +147,8 @@ def lib() -> C.CDLL:
         L.d4gs_blend_shard_bwd.argtypes = [P(ShardBlend), vp, vp, vp, vp, vp, vp]
         L.d4gs_frame_workspace_bytes.argtypes = [P(Dims), C.c_int64]
         L.d4gs_frame_workspace_bytes.restype = C.c_size_t
+        L.d4gs_frame_workspace_bytes_fwd.argtypes = [P(Dims), C.c_int64]
+        L.d4gs_frame_workspace_bytes_fwd.restype = C.c_size_t
         L.d4gs_forward.argtypes = [P(Dims), P(ProjIn), P(FrameIO), vp, C.c_size_t, C.c_int64, C.c_int64, vp]
         L.d4gs_backward.argtypes = [P(Dims), P(ProjIn), P(FrameIO), P(FrameGrads), P(LeafGrads), vp, C.c_size_t, C.c_int64,
                                     C.c_int64, vp]

@@ -38,7 +38,8 @@ struct FrameBufs {
   D4gsRaster raster;
   float *v_renders, *v_alphas, *isect_grad, *v_conics, *v_depths, *v_opac_act, *v_ctab, *partials;
   uint8_t *isect_live;
-  size_t bytes;
+  size_t bytes;      // the whole workspace
+  size_t fwd_bytes;  // its prefix d4gs_forward uses (the backward scratch follows)
 };
 
 FrameBufs carve(const D4gsDims *d, int64_t cap, void *ws) {
@@ -56,6 +57,7 @@ FrameBufs carve(const D4gsDims *d, int64_t cap, void *ws) {
   b.isect.sorted_gid = c.take<int32_t>(m), b.isect.sorted_emit = c.take<int32_t>(m);
   b.raster.last_ids = c.take<int32_t>(z.last_ids), b.raster.final_T = c.take<float>(z.final_T);
   b.raster.seg_state = z.seg_state > 0 ? c.take<float>(z.seg_state) : nullptr;  // few-tile launches: depth-segment boundary states
+  b.fwd_bytes = (c.off + 255) & ~(size_t)255;
   // backward scratch
   b.v_renders = c.take<float>(z.render_colors), b.v_alphas = c.take<float>(z.render_alphas);
   b.isect_grad = c.take<float>(m * (size_t)z.isect_grad_row), b.isect_live = c.take<uint8_t>((m + 3) & ~(size_t)3);
@@ -66,7 +68,7 @@ FrameBufs carve(const D4gsDims *d, int64_t cap, void *ws) {
 }
 
 int check_frame(const char *who, const D4gsDims *d, const D4gsProjIn *in, const D4gsFrameIO *io, void *ws, size_t ws_bytes,
-                int64_t cap) {
+                int64_t cap, bool forward_only = false) {
   D4gsSizes z;
   int rc = d4gs_query_sizes(d, &z);  // validates dims
   if (rc) return rc;
@@ -80,8 +82,10 @@ int check_frame(const char *who, const D4gsDims *d, const D4gsProjIn *in, const 
     d4gs_set_error("%s: the workspace must be 256-byte aligned", who);
     return D4GS_EINVAL;
   }
-  if (ws_bytes < carve(d, cap, nullptr).bytes) {
-    d4gs_set_error("%s: workspace of %zu bytes, need %zu (d4gs_frame_workspace_bytes)", who, ws_bytes, carve(d, cap, nullptr).bytes);
+  const FrameBufs need = carve(d, cap, nullptr);
+  if (ws_bytes < (forward_only ? need.fwd_bytes : need.bytes)) {
+    d4gs_set_error("%s: workspace of %zu bytes, need %zu (%s)", who, ws_bytes, forward_only ? need.fwd_bytes : need.bytes,
+                   forward_only ? "d4gs_frame_workspace_bytes_fwd; d4gs_backward needs d4gs_frame_workspace_bytes" : "d4gs_frame_workspace_bytes");
     return D4GS_ECAPACITY;
   }
   return D4GS_OK;
@@ -103,14 +107,21 @@ size_t d4gs_frame_workspace_bytes(const D4gsDims *dims, int64_t isect_capacity) 
   return carve(dims, isect_capacity, nullptr).bytes;
 }
 
+size_t d4gs_frame_workspace_bytes_fwd(const D4gsDims *dims, int64_t isect_capacity) {
+  D4gsSizes z;
+  if (d4gs_query_sizes(dims, &z)) return 0;
+  return carve(dims, isect_capacity, nullptr).fwd_bytes;
+}
+
 int d4gs_forward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, void *ws, size_t ws_bytes,
                  int64_t isect_capacity, int64_t max_tile_hint, void *stream_) {
-  int rc = check_frame("d4gs_forward", dims, in, io, ws, ws_bytes, isect_capacity);
+  int rc = check_frame("d4gs_forward", dims, in, io, ws, ws_bytes, isect_capacity, /*forward_only=*/true);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   FrameBufs b = carve(dims, isect_capacity, ws);
   bind_io(b, io, isect_capacity, max_tile_hint);
   if ((rc = d4gs_project_fwd_impl(dims, in, &b.proj, stream))) return rc;
+  if (isect_capacity < 0) return D4GS_OK;  // COUNT ONLY: io->n_isect (and means2d / radii) are what the caller wanted
   if ((rc = d4gs_bin_sort_impl(dims, &b.proj, &b.isect, stream))) return rc;
   if ((rc = d4gs_raster_fwd_impl(dims, &b.proj, &b.isect, &b.raster, stream))) return rc;
   if (io->blended) {

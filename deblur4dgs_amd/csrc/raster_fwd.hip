@@ -114,6 +114,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   D4GS_TCLK(_t0)
 #ifdef D4GS_TRACE
   unsigned long long _ts = 0, _tl = 0, _tc = 0, _ti = 0;
+  const unsigned long long _c0 = __builtin_amdgcn_s_memtime();  // shader clock (wall_clock64 = the constant 100 MHz one)
 #endif
   if (a.n_dev && (a.n_dev[0] > a.cap || (a.max_hint > 0 && a.n_dev[1] > a.max_hint))) return;
   const int n_tiles_s = a.tw * a.th;
@@ -286,7 +287,8 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   }
 #ifdef D4GS_TRACE
   if (a.trace && tid == 0) {
-    unsigned long long *tr = a.trace + (size_t)blockIdx.x * 8;
+    unsigned long long *tr = a.trace + (size_t)blockIdx.x * 10;
+    tr[8] = __builtin_amdgcn_s_memtime() - _c0;
     tr[0] = _t0, tr[1] = wall_clock64(), tr[3] = (unsigned long long)(end - start), tr[4] = _ts, tr[5] = _tl, tr[6] = _tc, tr[7] = _ti;
     tr[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
   }

@@ -90,6 +90,7 @@ class State:
     ws: object = None
     ws_ptr: int = 0
     ws_bytes: int = 0
+    want_grad: bool = True  # False: the render was issued under torch.no_grad() - FrameFn allocates the forward workspace only
     ws_cap: tuple = (0, 0)
     frame_io: dict = field(default_factory=dict)
     policy: object = None
@@ -240,7 +241,14 @@ def _deferred_poll(key, block: bool = False):
     return last
 
 
-_GRAPH_WATCH = None  # the GraphWatch whose capture is in progress (set by GraphWatch.capturing())
+_WATCH_TLS = threading.local()  # .watch: the GraphWatch whose capture is in progress ON THIS THREAD (GraphWatch.capturing());
+#                                 a capture is a per-thread, per-stream affair - a render captured on another thread must not
+#                                 attach its count copy to this one's watch
+_WARNED_UNWATCHED = False
+
+
+def _graph_watch():
+    return getattr(_WATCH_TLS, "watch", None)
 
 
 class GraphWatch:
@@ -267,13 +275,12 @@ class GraphWatch:
 
         @contextlib.contextmanager
         def cm():
-            global _GRAPH_WATCH
-            assert _GRAPH_WATCH is None, "nested GraphWatch captures"
-            _GRAPH_WATCH = self
+            assert _graph_watch() is None, "nested GraphWatch captures"
+            _WATCH_TLS.watch = self
             try:
                 yield self
             finally:
-                _GRAPH_WATCH = None
+                _WATCH_TLS.watch = None
 
         return cm()
 
@@ -462,13 +469,24 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
             # deferred check: launch at the guessed capacity, never wait.  The count travels to pinned memory behind
             # the launches and is looked at by a later call (not under stream capture: a graph replays this shape).
             launch(*guess)
-            if capturing and _GRAPH_WATCH is not None:
+            watch = _graph_watch()
+            if capturing and watch is None:
+                global _WARNED_UNWATCHED
+                if not _WARNED_UNWATCHED:
+                    _WARNED_UNWATCHED = True
+                    import warnings
+
+                    warnings.warn("deblur4dgs_amd: a render is being captured in a HIP graph outside `GraphWatch.capturing()`: its "
+                                  "replays keep the captured list capacities and skip their work silently if the scene outgrows them "
+                                  "(stale images, zero raster gradients).  Capture inside `with engine.GraphWatch().capturing():` and "
+                                  "call watch.replayed() / watch.check() around graph.replay().", RuntimeWarning, stacklevel=3)
+            if capturing and watch is not None:
                 # the copy of the counts becomes a node of the graph: every replay leaves them in this record's pinned buffer
                 # (a raw hipMemcpyAsync into memory pinned BEFORE the capture: neither an allocation nor torch's host-allocator
                 # bookkeeping may happen on a capturing stream)
-                host_n = _GRAPH_WATCH.take()
+                host_n = watch.take()
                 L.check(L.lib().d4gs_copy_counts(L.ptr(n_isect_dev()), host_n.data_ptr(), raw_stream(dev.index)), "copy_counts")
-                _GRAPH_WATCH.recs.append((key, host_n, guess[0], guess[1]))
+                watch.recs.append((key, host_n, guess[0], guess[1]))
             if not capturing:
                 with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
                     host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
@@ -481,6 +499,10 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
                     _DEFERRED.setdefault(key, []).append((host_n, ev, guess[0], guess[1]))
             _SIZE_STATS["calls"] += 1
             return guess
+    if torch.cuda.is_current_stream_capturing():  # what follows WAITS for the counts on the host: impossible under capture
+        raise RuntimeError("deblur4dgs_amd: a render of a shape that has no list-size guess yet (or without deferred_size_check) "
+                           "cannot be captured in a HIP graph - its intersection counts would have to be read on the host.  Run one "
+                           "eager step of the same shapes with RenderCfg.deferred_size_check=True first, then capture.")
     # The list sizes live on the device.  Read them back through pinned memory; when a previous call of the same
     # shape left a guess, launch binning + rasterization FIRST (sized by the guess, checked on the device) and
     # wait for the counts afterwards, so the GPU never idles on the host round trip (70 us per render).
@@ -488,7 +510,7 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
     if guess is not None:
         launch(*guess)
     elif count_needs_launch:
-        launch(0, 0)
+        launch(-1, 0)  # capacity < 0: d4gs_forward returns after the projection + counting (no binning / composite / blend launches)
     host_n = _pinned_counts(dev)
     host_n.copy_(n_isect_dev(), non_blocking=True)
     ev = torch.cuda.Event()
@@ -641,8 +663,12 @@ class FrameFn(torch.autograd.Function):
         if blended:
             fio.policy = pol
 
+        # a forward nobody will differentiate (torch.no_grad(): validation, the viewer's render_view) needs none of the backward's
+        # scratch - about half of the workspace, pinned by the returned state for as long as the caller keeps it
+        ws_bytes_of = lib.d4gs_frame_workspace_bytes if st.want_grad else lib.d4gs_frame_workspace_bytes_fwd
+
         def launch(cap, max_hint):
-            nbytes = lib.d4gs_frame_workspace_bytes(C.byref(dims), cap)
+            nbytes = ws_bytes_of(C.byref(dims), cap)
             st.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
             st.ws_ptr = (st.ws.data_ptr() + 255) & ~255
             st.ws_bytes = nbytes

@@ -105,6 +105,7 @@ def render_exposure(
         # ONE autograd node over d4gs_forward / d4gs_backward: same kernels and bits as the staged chain below, a fraction
         # of its host work.  `means2d` is then a plain tensor; its gradient goes to st.xys_sink / st.v_means2d.
         st = State(cfg)
+        st.want_grad = torch.is_grad_enabled()
         pol = (reference_policy(cfg.NCH) if policy is None else list(policy)) if blend else None
         bl, acc, rc, ra = FrameFn.apply(st, pol, means, quats, scales, opacities, colors, motion_coefs, rots, transls, times, RTs,
                                         w2c, Kmat, background)

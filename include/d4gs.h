@@ -404,6 +404,10 @@ typedef struct D4gsFrameGrads {
   int32_t stats_batch_size, stats_update_max_radii, row_mode;
 } D4gsFrameGrads;
 size_t d4gs_frame_workspace_bytes(const D4gsDims *dims, int64_t isect_capacity);
+/* The prefix of that workspace d4gs_forward alone touches (everything but the backward's scratch: image-gradient stack, per-
+ * intersection gradient rows, per-instance gradients, block partials - roughly half): a forward that will never be followed by
+ * d4gs_backward (validation, viewer) may pass a workspace of this size. */
+size_t d4gs_frame_workspace_bytes_fwd(const D4gsDims *dims, int64_t isect_capacity);
 int d4gs_forward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, void *workspace, size_t ws_bytes,
                  int64_t isect_capacity, int64_t max_tile_hint, void *stream);
 int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, const D4gsFrameGrads *g,

@@ -6,8 +6,7 @@ from deblur4dgs_amd.synth import make_scene
 from deblur4dgs_amd.exposure import render_exposure
 import bench
 
-cfg = bench.CONFIGS["cfg2"] if hasattr(bench, "CONFIGS") else None
-sc = make_scene(300_000, 300_000, 6, 8, 512, 288, seed=0)
+sc = bench.scene_of("cfg2")  # the benched scene itself (seed 1001): bench.py quotes these statistics beside its timing
 dev = "cuda:0"
 L = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
 res = render_exposure(L["means"], L["quats"], L["scales"], L["opacities"], L["colors"], 3, L["motion_coefs"], L["rots"],
@@ -135,7 +134,11 @@ for nb in NCHK:
           f"{int(c.max(-1).values.sum())} (box), {int(cg.max(-1).values.sum())} (exact); per-wave barrier-max over waves (box): {int(c.max(-1).values.max(-1).values.sum() * 4)}")
 
 import json
-stats = {"config": "cfg2 (seed 0 scene of the same distribution)", "n_isect": int(n),
+import hashlib
+from deblur4dgs_amd import _lib as _L
+stats = {"config": "cfg2 (the benched scene: bench.scene_of('cfg2'), seed 1001)", "n_isect": int(n),
+         "lib_sha256": hashlib.sha256(open(_L.LIB_PATH, "rb").read()).hexdigest(),
+         "bwd_nominal_pairs": int(K_hits) * 64,
          "bwd_quadrant_replays": int(K_hits), "bwd_replays_with_no_valid_lane": K_zero / K_hits,
          "bwd_valid_pairs": int(K_valid), "bwd_active_lane_fraction": K_valid / (64.0 * K_hits),
          "bwd_active_lane_fraction_of_nonempty_replays": K_valid / (64.0 * (K_hits - K_zero)),
@@ -143,5 +146,5 @@ stats = {"config": "cfg2 (seed 0 scene of the same distribution)", "n_isect": in
          "note": "valid = alpha >= 1/255, sigma >= 0, inside the image, at or before the pixel's last contributor; a replay = "
                  "one (8x8 quadrant wave, splat) iteration of k_raster_bwd_q"}
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(stats, open("gpurun_out/lane_stats_cfg2.json", "w"), indent=1)
+json.dump(stats, open(os.environ.get("LANE_STATS_OUT", "gpurun_out/lane_stats_cfg2.json"), "w"), indent=1)
 print(json.dumps(stats))

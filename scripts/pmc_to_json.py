@@ -36,4 +36,7 @@ sq = parse(f"gpurun_out/pmc_{tag}_sq.txt")
 sq["lib_sha256"] = lib_sha
 json.dump(sq, open(f"profiles/{rnd}_pmc_sq_{cfg}.json", "w"), indent=1)
 json.dump({"lib_sha256": lib_sha, "round": rnd}, open("profiles/pmc_current.json", "w"), indent=1)
+lane = f"gpurun_out/{tag}_lane_stats_{cfg}.json"  # scripts/pair_stats.py of the same round (stamped with the library hash itself)
+if os.path.exists(lane):
+    json.dump(json.load(open(lane)), open(f"profiles/{rnd}_lane_stats_{cfg}.json", "w"), indent=1)
 print("kernels:", sorted(doc[cfg]["kernels"]))

@@ -21,5 +21,5 @@ scripts/pmc_run.sh ${tag}_fetch FETCH_SIZE > /dev/null
 scripts/pmc_run.sh ${tag}_write WRITE_SIZE > /dev/null
 scripts/pmc_run.sh ${tag}_sq SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY > /dev/null
 rm -rf gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/pmc_${tag}_sq
-python scripts/pair_stats.py > gpurun_out/${tag}_pair_stats.txt 2>&1
+LANE_STATS_OUT=gpurun_out/${tag}_lane_stats_cfg2.json python scripts/pair_stats.py > gpurun_out/${tag}_pair_stats.txt 2>&1
 ls -la gpurun_out | grep $tag

@@ -23,7 +23,7 @@ times = leaves["times"][::a.share].detach().clone().requires_grad_()
 RTs = leaves["RTs"][::a.share].detach().clone().requires_grad_()
 bg = torch.ones(3, device=dev)
 NB = 1 << 16
-RW = 8 if a.fwd else 4
+RW = 10 if a.fwd else 4
 trace = torch.zeros(NB * RW, dtype=torch.int64, device=dev)
 
 
@@ -68,6 +68,8 @@ if a.fwd:
         v = t[:, col].double()[act] / 100.0
         print(f"  per-WG time in {nm}: p10 {float(v.quantile(0.1)):.1f} p50 {float(v.median()):.1f} p90 {float(v.quantile(0.9)):.1f} us")
 if a.fwd:
+    mhz = t[:, 8].double()[act] / life[act].clamp(min=1e-3)
+    print(f"  shader clock over the WG lifetimes (s_memtime ticks per us of wall clock): p10 {float(mhz.quantile(0.1)):.0f} p50 {float(mhz.median()):.0f} p90 {float(mhz.quantile(0.9)):.0f} MHz")
     it = t[:, 7].double()[act]
     comp = t[:, 6].double()[act] / 100.0
     print(f"  walk iterations of wave 0 per WG: p10 {int(it.quantile(0.1))} p50 {int(it.median())} p90 {int(it.quantile(0.9))}; compositing ns per iteration: p50 {float((1e3 * comp / it.clamp(min=1)).median()):.0f}")

@@ -134,7 +134,13 @@ def test_one_call_entry_points_validate_before_any_hip_call(lib):
     fake = 0x10000
     pin = L.ProjIn(**{n: fake for n, _ in L.ProjIn._fields_})
     io = L.FrameIO(**{n: fake for n in ("renders", "alphas", "means2d", "radii", "n_isect")})
-    assert lib.d4gs_forward(C.byref(d), C.byref(pin), C.byref(io), C.c_void_p(fake), small - 1, 0, 0, None) == -3  # D4GS_ECAPACITY
+    # the forward alone needs only the prefix of the workspace in front of the backward's scratch (validation / viewer renders)
+    lib.d4gs_frame_workspace_bytes_fwd.restype = C.c_size_t
+    lib.d4gs_frame_workspace_bytes_fwd.argtypes = [C.POINTER(L.Dims), C.c_int64]
+    fwd_small = lib.d4gs_frame_workspace_bytes_fwd(C.byref(d), 0)
+    assert 0 < fwd_small < small and fwd_small % 256 == 0
+    assert small - fwd_small >= 4 * (2 * 64 * 48 * 5 + 2 * 1000 * 4)  # at least the image-gradient stack and the per-instance rows
+    assert lib.d4gs_forward(C.byref(d), C.byref(pin), C.byref(io), C.c_void_p(fake), fwd_small - 1, 0, 0, None) == -3  # D4GS_ECAPACITY
     assert b"workspace" in lib.d4gs_last_error()
     assert lib.d4gs_forward(C.byref(d), C.byref(pin), C.byref(io), C.c_void_p(fake + 8), small, 0, 0, None) == -1
     assert b"aligned" in lib.d4gs_last_error()

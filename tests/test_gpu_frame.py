@@ -112,3 +112,43 @@ def test_scene_model_uses_the_one_call_path_and_keeps_the_side_channels():
     assert set(res[True]) == set(res[False]) and "move_model.RT_head0.2.bias" in res[True]
     for k in res[True]:
         assert torch.equal(res[True][k].detach(), res[False][k].detach()), k
+
+
+def test_no_grad_render_takes_the_forward_workspace_only_and_the_cold_call_only_counts():
+    """(1) a render under torch.no_grad() (validation, the viewer's render_view) must not allocate - and pin through the
+    returned state - the backward's scratch; (2) the cold call of a shape (no size guess yet) counts with a d4gs_forward that stops
+    after the projection (capacity < 0) instead of running the whole frame at capacity 1 first.  Same image bit for bit."""
+    import ctypes as C
+
+    from deblur4dgs_amd import _lib as L
+    from deblur4dgs_amd import engine
+
+    dev = torch.device("cuda:0")
+    N, G, K_, S, W, H = 6000, 4000, 3, 3, 160, 96
+    sc = make_scene(N, G, K_, S, W, H, seed=35)
+    K = sc["K"].to(dev)
+    lv = _leaves(sc, dev)
+    engine._SIZE_GUESS.clear()
+    lib = L.lib()
+    lib.d4gs_profile_enable(1)
+    with torch.no_grad():
+        r_ng = _render(lv, K, W, H, True)  # cold: counting call + exact launch
+    torch.cuda.synchronize()
+    lib.d4gs_profile_enable(0)
+    buf = C.create_string_buffer(1 << 16)
+    lib.d4gs_profile_collect(buf, C.c_size_t(len(buf)))
+    launches = {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().splitlines()}
+    assert launches["k_project_fwd"] == 2 and launches["k_raster_fwd_r"] == 1 and launches["k_emit"] == 1, launches
+    r_g = _render(lv, K, W, H, True)
+    torch.cuda.synchronize()
+    assert torch.equal(r_ng["blended"], r_g["blended"]) and torch.equal(r_ng["renders"], r_g["renders"])
+    st_ng, st_g = r_ng["state"], r_g["state"]
+    dims = st_g.cfg.dims()
+    assert st_g.ws_bytes == lib.d4gs_frame_workspace_bytes(C.byref(dims), st_g.ws_cap[0])
+    assert st_ng.ws_bytes == lib.d4gs_frame_workspace_bytes_fwd(C.byref(dims), st_ng.ws_cap[0])
+    cap = st_ng.n_isect
+    full, fwd = lib.d4gs_frame_workspace_bytes(C.byref(dims), cap), lib.d4gs_frame_workspace_bytes_fwd(C.byref(dims), cap)
+    assert fwd < 0.7 * full, (fwd, full)  # the gradient rows alone are 40 bytes per intersection against 20 of lists
+    (r_g["blended"].sum()).backward()  # and the differentiable one still has its scratch
+    torch.cuda.synchronize()
+    assert float(lv["means"].grad.abs().sum()) > 0
