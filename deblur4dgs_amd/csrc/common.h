@@ -437,6 +437,22 @@ __device__ __forceinline__ void wave_sum_store(float (&v)[R], float *dst, int la
   wave_sum_store(v, dst, 0, lane);
 }
 
+// ---- a staged splat's tight alpha >= 1/255 box as 4 x f16 in tile-local pixels (raster kernels) ----
+__device__ __forceinline__ uint2 d4gs_pack_box(float x0, float x1, float y0, float y1) {
+  const float lo = -32.f, hi = 48.f;
+  x0 = fminf(fmaxf(x0 - 0.04f, lo), hi), x1 = fminf(fmaxf(x1 + 0.04f, lo), hi);
+  y0 = fminf(fmaxf(y0 - 0.04f, lo), hi), y1 = fminf(fmaxf(y1 + 0.04f, lo), hi);
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 a = {(_Float16)x0, (_Float16)x1}, b = {(_Float16)y0, (_Float16)y1};
+  return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+}
+__device__ __forceinline__ float4 d4gs_unpack_box(uint2 p) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 a = __builtin_bit_cast(h2, p.x), b = __builtin_bit_cast(h2, p.y);
+  return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+
+
 #define D4GS_LAUNCH(name, kernel, grid, block, lds, stream, ...)            \
   do {                                                                        \
     ProfScope _ps(name, stream);                                              \

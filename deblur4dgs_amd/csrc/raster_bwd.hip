@@ -18,6 +18,8 @@
 //     fabric-level atomic traffic (device-scope float atomics are serialised memory-side on MI355X's 8 XCDs).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -104,7 +106,15 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
   constexpr int DP = (D + 3) & ~3;
   constexpr int DV = DP / 4;
   constexpr int R = 6 + NCH;
-  constexpr int RP = (R + 1) | 1;
+  // >= 16 channels (the reference's 17-channel training renders): 4 waves per SIMD instead of 3 (round 4).  The kernel's time goes
+  // with 1 / occupancy and its workgroup needed 50.4 KB of LDS and 140 VGPRs; an 8-hit `fac` tile (the MFMA's other 8 columns idle:
+  // twice the matrix instructions per hit), the staged boxes as 4 x f16 and an even slab stride bring it to 40.6 KB / 113 VGPRs
+  // without scratch: refdefault's backward 1 066 -> 1 023 us, cfg2 with 17 channels 1 315 -> 1 258 (D4GS_BWD16_4W=0: the old shape).
+#ifndef D4GS_BWD16_4W
+#define D4GS_BWD16_4W 1
+#endif
+  constexpr bool W4 = D4GS_BWD16_4W && D >= 16;
+  constexpr int RP = W4 ? (R + 1) : ((R + 1) | 1);
   constexpr int NB = 64;  // splats per batch
   // With >= 16 colour channels the colour gradients V_c[j] = sum_p vo[c][p] * fac[p][j] of channels 0..15 leave the
   // VALU: they are a [16 ch x 64 px] x [64 px x 16 hits] product, A = this quadrant's image gradient (fixed for the
@@ -113,14 +123,15 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
   constexpr int MC = D >= 16 ? 16 : 0;        // channels reduced on the matrix pipe
   constexpr int RV = R - MC;                  // rows reduced on the VALU
   constexpr int CB = MC ? RV + 1 : 6;         // slab column of channel 0 (VALU rows, their pad slot, then colours)
-  constexpr int FS = 17;                      // fac tile [64 px][16 hits], row stride (bank-conflict padding)
+  constexpr int MH = W4 ? 8 : 16;             // hits parked per flush (the MFMA's 16 columns: the upper 8 idle when MH = 8)
+  constexpr int FS = MH + 1;                  // fac tile [64 px][MH hits], row stride (bank-conflict padding)
   static_assert(!MC || CB + MC <= RP, "slab row too short");
   constexpr float LN2 = 0.6931471805599453f;
   __shared__ float sfac[MC ? 4 * 64 * FS : 1];
-  __shared__ int shit[MC ? 4 * 16 : 1];
+  __shared__ int shit[MC ? 4 * MH : 1];
   __shared__ float4 sg0[NB];
   __shared__ float4 sg1[NB];
-  __shared__ float4 sbox[NB];
+  __shared__ typename std::conditional<W4, uint2, float4>::type sbox[NB];  // W4: 4 x f16, tile-local (the forward's pack_box)
   __shared__ float4 scol[NB * DV];
   __shared__ float sgrad[4 * NB * RP];
   __shared__ int shi[4];
@@ -151,7 +162,9 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
   const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
   const bool inside = x < a.width && y < a.height;
   const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
-  const float qlx = (float)qx0 + 0.5f, qhx = (float)qx0 + 7.5f, qly = (float)qy0 + 0.5f, qhy = (float)qy0 + 7.5f;
+  // (W4: boxes and quadrant bounds relative to the tile origin, where 4 x f16 resolve them)
+  const float tx0f = W4 ? (float)(tx * D4GS_TILE) : 0.f, ty0f = W4 ? (float)(ty * D4GS_TILE) : 0.f;
+  const float qlx = (float)qx0 - tx0f + 0.5f, qhx = (float)qx0 - tx0f + 7.5f, qly = (float)qy0 - ty0f + 0.5f, qhy = (float)qy0 - ty0f + 7.5f;
 
   float T = 1.f, va = 0.f, vo[NCH], bsum = 0.f;
   int last = -1;
@@ -204,7 +217,7 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
   // A fragments (lane l holds A[row = l & 15][k = l >> 4]): channel l & 15 at quadrant pixel 4 kk + (l >> 4)
   float afrag[MC ? 16 : 1];
   float *myfac = sfac + (MC ? wv * 64 * FS : 0);
-  int *myhit = shit + (MC ? wv * 16 : 0);
+  int *myhit = shit + (MC ? wv * MH : 0);
   int nh = 0;
   if constexpr (MC > 0) {
     static_assert(256 * MC <= 4 * NB * RP, "exchange buffer");
@@ -219,11 +232,12 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
     if constexpr (MC > 0) {
       __builtin_amdgcn_wave_barrier();
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // even / odd k-steps, added in fixed order
-      const float *bp = myfac + (lane >> 4) * FS + (lane & 15);
+      const bool col = (lane & 15) < MH;  // (MH = 8: columns 8..15 of the B operand are zeros)
+      const float *bp = myfac + (lane >> 4) * FS + (col ? (lane & 15) : 0);
 #pragma unroll
       for (int kk = 0; kk < 16; kk += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], bp[4 * kk * FS], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk + 1], bp[(4 * kk + 4) * FS], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], col ? bp[4 * kk * FS] : 0.f, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk + 1], col ? bp[(4 * kk + 4) * FS] : 0.f, acc1, 0, 0, 0);
       }
       acc0 += acc1;
       const int n = lane & 15;
@@ -264,8 +278,12 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
           ex = sqrtf(2.f * tau * q1.z * idet) + 1e-3f;
           ey = sqrtf(2.f * tau * q1.x * idet) + 1e-3f;
         }
-        sbox[tid] = ex < 0.f ? make_float4(1e30f, -1e30f, 1e30f, -1e30f)
-                             : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
+        if constexpr (W4)
+          sbox[tid] = ex < 0.f ? d4gs_pack_box(1e30f, -1e30f, 1e30f, -1e30f)
+                               : d4gs_pack_box(q0.x - ex - tx0f, q0.x + ex - tx0f, q0.y - ey - ty0f, q0.y + ey - ty0f);
+        else
+          sbox[tid] = ex < 0.f ? make_float4(1e30f, -1e30f, 1e30f, -1e30f)
+                               : make_float4(q0.x - ex, q0.x + ex, q0.y - ey, q0.y + ey);
         const float4 *cp = reinterpret_cast<const float4 *>(a.ctab + (size_t)gid * DP);
 #pragma unroll
         for (int v = 0; v < DV; v++) {
@@ -286,7 +304,9 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
       const int jj = k * 64 + lane;
       bool hit = false;
       if (jj < nb && bh - jj <= whi) {
-        const float4 bx = sbox[jj];
+        float4 bx;
+        if constexpr (W4) bx = d4gs_unpack_box(sbox[jj]);
+        else bx = sbox[jj];
         hit = (bx.x <= qhx) && (bx.y >= qlx) && (bx.z <= qhy) && (bx.w >= qly);
       }
       unsigned long long m = __ballot(hit);
@@ -337,8 +357,8 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
         row[5] = vs;
         wave_sum_store(row, sgrad, (wvs * NB + j) * RP, lane);
         if constexpr (MC > 0) {
-          if (++nh == 16) {
-            flush(16);
+          if (++nh == MH) {
+            flush(MH);
             nh = 0;
           }
         }
@@ -378,7 +398,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   raster_bwd_q_body<D, DEPTH>(a);
 }
 template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) k_raster_bwd_q(const RasterBwdArgs a) {
+__global__ void __launch_bounds__(256)
+#if defined(D4GS_BWD16_4W) && D4GS_BWD16_4W
+__attribute__((amdgpu_waves_per_eu(D >= 16 ? 4 : 1, D >= 16 ? 4 : 10)))
+#endif
+k_raster_bwd_q(const RasterBwdArgs a) {
   raster_bwd_q_body<D, DEPTH>(a);
 }
 // the same two over (tile, depth segment) workgroups

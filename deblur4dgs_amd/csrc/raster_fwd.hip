@@ -71,25 +71,11 @@ __device__ __forceinline__ int xcd_remap(int b, int n_blocks) {
 // arrays fit 20 KB and 8 workgroups share a CU).  Only the range around the tile matters, so the bounds are clamped to
 // [-32, 48] (f16 spacing <= 1/32 there) and widened by 0.04 px before the round-to-nearest conversion: the packed box
 // always contains the exact one.  It is a filter - the per-pixel alpha test decides - so the image does not change.
-__device__ __forceinline__ uint2 pack_box(float x0, float x1, float y0, float y1) {
-  const float lo = -32.f, hi = 48.f;
-  x0 = fminf(fmaxf(x0 - 0.04f, lo), hi), x1 = fminf(fmaxf(x1 + 0.04f, lo), hi);
-  y0 = fminf(fmaxf(y0 - 0.04f, lo), hi), y1 = fminf(fmaxf(y1 + 0.04f, lo), hi);
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 a = {(_Float16)x0, (_Float16)x1}, b = {(_Float16)y0, (_Float16)y1};
-  return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
-}
-__device__ __forceinline__ float4 unpack_box(uint2 p) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 a = __builtin_bit_cast(h2, p.x), b = __builtin_bit_cast(h2, p.y);
-  return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
-}
-
 template <bool PACKED> struct BoxT;
 template <> struct BoxT<true> {
   typedef uint2 type;
-  static __device__ __forceinline__ uint2 pack(float x0, float x1, float y0, float y1) { return pack_box(x0, x1, y0, y1); }
-  static __device__ __forceinline__ float4 unpack(uint2 p) { return unpack_box(p); }
+  static __device__ __forceinline__ uint2 pack(float x0, float x1, float y0, float y1) { return d4gs_pack_box(x0, x1, y0, y1); }
+  static __device__ __forceinline__ float4 unpack(uint2 p) { return d4gs_unpack_box(p); }
 };
 template <> struct BoxT<false> {
   typedef float4 type;

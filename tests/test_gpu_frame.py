@@ -148,7 +148,9 @@ def test_no_grad_render_takes_the_forward_workspace_only_and_the_cold_call_only_
     assert st_ng.ws_bytes == lib.d4gs_frame_workspace_bytes_fwd(C.byref(dims), st_ng.ws_cap[0])
     cap = st_ng.n_isect
     full, fwd = lib.d4gs_frame_workspace_bytes(C.byref(dims), cap), lib.d4gs_frame_workspace_bytes_fwd(C.byref(dims), cap)
-    assert fwd < 0.7 * full, (fwd, full)  # the gradient rows alone are 40 bytes per intersection against 20 of lists
+    # what a no_grad render does not allocate: the gradient rows (40 B per intersection), the image-gradient stack, the
+    # per-instance gradient buffers
+    assert full - fwd >= 40 * cap + 4 * S * H * W * 5 + 4 * S * N * 4, (fwd, full)
     (r_g["blended"].sum()).backward()  # and the differentiable one still has its scratch
     torch.cuda.synchronize()
     assert float(lv["means"].grad.abs().sum()) > 0
