@@ -130,6 +130,40 @@ def test_subsamples_in_two_calls_equal_one_call(scene):
     assert torch.equal(full, torch.cat([lo, hi], 0))  # sub-samples are independent (the sharding premise)
 
 
+def test_one_subsample_per_call_equals_the_full_frame(scene):
+    """BASELINE config 4's premise at its extreme - one sub-sample per rank: the rank-side kernel mappings of few-tile /
+    few-sub-sample launches (k_project_bwd's sub-groups, the depth-segmented composite backward, 1-instance-per-lane binning
+    chunks) must reproduce the single call: sub-sample IMAGES bit for bit, and the gradients of a loss on the stack - summed
+    over the S one-sub-sample calls, as the ranks' all-reduce sums them - equal to the single call's up to fp32 summation order
+    and the segments' hand-off rounding."""
+    if scene["name"] != "cfg2":
+        pytest.skip("the one-sub-sample shard of cfg2 = BASELINE config 4")
+    from tests.util import rel_err
+
+    S, dev = scene["S"], scene["means"].device
+    names = ("means", "quats", "scales", "opacities", "colors", "motion_coefs", "rots", "transls")
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(S, scene["H"], scene["W"], 4, generator=g).to(dev)
+
+    def run(sel_list):
+        lv = {k: scene[k].detach().clone().requires_grad_() for k in names}
+        sc = dict(scene, **lv)
+        outs = []
+        for sel in sel_list:
+            r = _render(sc, sel=sel, blend=False, fused=True)
+            (r["renders"] * w[sel]).sum().backward()
+            outs.append(r["renders"].detach())
+        torch.cuda.synchronize()
+        return torch.cat(outs, 0), {k: lv[k].grad.clone() for k in names}
+
+    full_img, full_g = run([slice(0, S)])
+    one_img, one_g = run([slice(s, s + 1) for s in range(S)])
+    assert torch.equal(full_img, one_img)
+    for k in names:
+        r = rel_err(one_g[k], full_g[k])
+        assert r <= 2e-5, (k, r)
+
+
 def test_full_size_subsample_matches_scalar_c_oracle(scene):
     """One exposure sub-sample of cfg2 (300 k Gaussians, 288x512) and of cfg3 (720x1280) against the scalar C
     restatement in fp64 - the only oracle fast enough at this size: images and all per-Gaussian gradients of the
