@@ -469,6 +469,7 @@ def main():
             if mode_flag["deferred"] and not dry:
                 engine.check_deferred()  # this step's list sizes, verified behind its launches (raises on overflow)
 
+        eager_step = step
         for _ in range(warmup):
             step()
         sync()
@@ -480,6 +481,12 @@ def main():
             step()
             sync()
             real_state = last["st"]
+
+            def grad_signature():  # one number per leaf: what a replay of the captured step must reproduce
+                return torch.stack([v.grad.detach().double().abs().sum() if v.grad is not None else torch.zeros((), dtype=torch.float64, device=dev)
+                                    for v in leaves.values()])
+
+            ref_sig = grad_signature()
             mode_flag["deferred"] = deferred
             if not dry:
                 side = torch.cuda.Stream()
@@ -514,7 +521,8 @@ def main():
                     captured = True
                 else:
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
+                    watch = engine.GraphWatch()  # the replays keep reporting their list sizes (an outgrown capture raises)
+                    with watch.capturing(), torch.cuda.graph(graph):
                         gstep()
                     captured = True
             except Exception as e:  # (never seen at world size 1; an N > 1 capture has not run on this pool's 1-GPU boxes)
@@ -540,8 +548,24 @@ def main():
 
                 for _ in range(3):
                     step()
+                watch.replayed()
                 sync()
-            elif sharder is not None:
+                watch.check()
+                # the captured step - RCCL collectives included at N > 1 - must reproduce the eager step's gradients before
+                # its time may stand for the frame; otherwise every rank goes back to the eager step
+                got_sig = grad_signature()
+                same = bool(((got_sig - ref_sig).abs() <= 1e-4 * ref_sig.abs().clamp(min=1e-30)).all().item())
+                if use_dist:
+                    ok = torch.tensor([1 if same else 0], device=dev, dtype=torch.int32)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    same = bool(int(ok.item()))
+                if not same:
+                    captured = False
+                    graph_note["fallback"] = ("the captured step did not reproduce the eager step's gradients (leaf |grad| sums off by "
+                                              f"up to {float(((got_sig - ref_sig).abs() / ref_sig.abs().clamp(min=1e-30)).max()):.2e}); timed the eager step")
+                    sys.stderr.write(graph_note["fallback"] + "\n")
+                    step = eager_step
+            if not captured and sharder is not None:
                 sharder.deferred_size_check = deferred
         if profile:
             lib.d4gs_profile_enable(2)  # HIP events around the rasterization kernels only: timing EVERY kernel costs two

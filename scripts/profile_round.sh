@@ -17,6 +17,16 @@ for cfg in cfg2 cfg3 cfg5 refdefault; do
   [ -n "$csv" ] && cp $csv gpurun_out/${tag}_kernel_stats_$cfg.csv
   rm -rf gpurun_out/${tag}_prof_$cfg
 done
+# one rank's share of an exposure-sharded cfg2 frame (BASELINE config 4: S / P sub-samples, no collectives) under the same profiler
+for sh in 4 8; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_share$sh -o r -- python $R/bench.py --share $sh --steps 10 --warmup 3 --no-cpu-baseline --no-profile > $R/gpurun_out/${tag}_bench_under_rocprof_share$sh.json 2>>$R/gpurun_out/${tag}_prof.err)
+  db=$(find gpurun_out/${tag}_prof_share$sh -name "*.db" | head -1)
+  [ -n "$db" ] && python scripts/rocpd_summary.py $db > gpurun_out/${tag}_kernel_stats_share$sh.csv
+  rm -rf gpurun_out/${tag}_prof_share$sh
+done
+python scripts/shard_floor.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_shard_floor.txt
+python bench.py --graph --steps 30 --warmup 5 --no-cpu-baseline 2>>gpurun_out/${tag}_bench.err | tail -1 > gpurun_out/${tag}_bench_graph_cfg2.json
+python bench.py --force-dist --graph --steps 30 --warmup 5 --no-cpu-baseline 2>>gpurun_out/${tag}_bench.err | tail -1 > gpurun_out/${tag}_bench_graph_rccl_world1_cfg2.json
 scripts/pmc_run.sh ${tag}_fetch FETCH_SIZE > /dev/null
 scripts/pmc_run.sh ${tag}_write WRITE_SIZE > /dev/null
 scripts/pmc_run.sh ${tag}_sq SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY > /dev/null
