@@ -93,6 +93,11 @@ def parse():
                     help="run the N > 1 control flow of this script on CPU tensors over gloo (tests/test_parallel_gloo.py): "
                          "process-group set-up, the sharded step's collectives, the graph-capture fallback agreement, max-over-ranks "
                          "timing, ONE JSON line - with the render replaced by a synthetic differentiable image.  Measures nothing.")
+    ap.add_argument("--no-peaks", action="store_true", help="skip d4gs_measure_peaks (profiler passes: keeps its kernels out of the trace)")
+    ap.add_argument("--spatial-order", action="store_true",
+                    help="secondary measurement: the same Gaussians in the order deblur4dgs_amd.control.spatial_order_step leaves them in "
+                         "(3-D Morton curve of the means, per set) instead of the generator's random order; the headline keeps the "
+                         "random order")
     ap.add_argument("--share", type=int, default=1, metavar="P",
                     help="diagnostic (not the headline): render only rank 0's share {s : s %% P == 0} of the exposure sub-samples, no "
                          "collectives - the device work ONE rank of an exposure-sharded frame at world size P executes "
@@ -431,13 +436,23 @@ def main():
             sys.stderr.write(f"d4gs_measure_peaks failed: {e!r}\n")
             return None
 
-    peaks = measured_peaks() if rank == 0 and not dry else None
+    peaks = measured_peaks() if rank == 0 and not dry and not args.no_peaks else None
 
     def measure(mode, steps, warmup, profile):
         """-> (seconds for `steps` steps: max over ranks, live kernel timings, last state)"""
         views = use_dist and mode == "views"
         sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0, channels=channels,
                                                 scale_mul=args.scale_mul)
+        if args.spatial_order:  # the product's control.spatial_order_step, applied to the synthetic scene (all Gaussians dynamic or all
+            from deblur4dgs_amd.control import morton_permutation  # static in the BASELINE configs; refdefault: per set)
+
+            with torch.no_grad():
+                m = leaves["means"].detach()
+                perm = torch.cat([morton_permutation(m[:G]), G + morton_permutation(m[G:])]) if 0 < G < N else morton_permutation(m)
+                for k in ("means", "quats", "scales", "opacities", "colors", "motion_coefs"):
+                    if k in leaves:
+                        pk = perm if leaves[k].shape[0] == N else morton_permutation(m[:G])
+                        leaves[k] = leaves[k].detach()[pk].clone().requires_grad_()
         if args.share > 1 and not use_dist:
             for k in ("times", "RTs"):
                 if k in leaves:
@@ -617,6 +632,8 @@ def main():
                     if not views_primary else f"views sharded x{world} (data parallel), RCCL gradient all-reduce")},
         "instances_per_s": value * S,
     }
+    if args.spatial_order:
+        out["config"]["workload"] += "; Gaussians in 3-D Morton order (control.spatial_order_step)"
     if args.share > 1:
         out["metric"] = f"DIAGNOSTIC rank-0 share of {name} at world size {args.share} (no collectives), Gaussians / t"
         out["config"]["workload"] += f"; ONLY sub-samples s % {args.share} == 0 rendered (--share)"
@@ -669,9 +686,9 @@ def main():
                         "field only admits hbm|mfma and 157.3 TFLOP/s is both the fp32 vector and the fp32-input MFMA peak)",
                         "achieved": flops / t_k / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS,
-                        "peak_measured": peaks["fp32_pk_fma_tflops"] if peaks else None,
-                        "frac_of_measured": (flops / t_k / 1e12 / peaks["fp32_pk_fma_tflops"]) if peaks else None,
-                        "peak_measured_plain_fma": peaks["fp32_fma_tflops"] if peaks else None,
+                        "peak_measured": max(peaks["fp32_pk_fma_tflops"], peaks["fp32_fma_tflops"]) if peaks else None,
+                        "frac_of_measured": (flops / t_k / 1e12 / max(peaks["fp32_pk_fma_tflops"], peaks["fp32_fma_tflops"])) if peaks else None,
+                        "peak_measured_detail": {"v_pk_fma_f32": peaks["fp32_pk_fma_tflops"], "v_fma_f32": peaks["fp32_fma_tflops"]} if peaks else None,
                         "traffic": tr["total_1x"] if tr else None,
                         "traffic_detail": tr, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
                         "note": "NOMINAL work-equivalent fraction (SURVEY 8d): 90 flop x 256 pixels for every (tile, splat) "

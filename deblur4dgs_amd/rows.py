@@ -45,6 +45,15 @@ class RowPlan:
             self.src = torch.cat(parts).to(torch.int32)
             self.n_out = self.src.shape[0]
 
+    @classmethod
+    def from_permutation(cls, perm: torch.Tensor) -> "RowPlan":
+        """A plan that only REORDERS rows (out[i] = in[perm[i]]): the spatial re-ordering step (control.spatial_order_step)."""
+        p = cls.__new__(cls)
+        p.n_in = p.n_keep = p.n_out = perm.shape[0]
+        p.n_dup = p.n_split = 0
+        p.src = perm.to(torch.int32).contiguous()
+        return p
+
     @property
     def n_new(self) -> int:
         return self.n_dup + 2 * self.n_split

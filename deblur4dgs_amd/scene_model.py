@@ -103,6 +103,15 @@ class GaussianParams(nn.Module):
         self.params["opacities"].data.fill_(float(new_val))
         return {"opacities": self.params["opacities"]}
 
+    def reorder_params(self, plan):
+        """Rows permuted by `plan` (rows.RowPlan.from_permutation): the set of Gaussians is unchanged, only their order in
+        memory (control.spatial_order_step).  Returns {name: new Parameter}."""
+        out = {}
+        for name in list(self.params.keys()):
+            out[name] = nn.Parameter(plan.gather(self.params[name].detach()))
+            self.params[name] = out[name]
+        return out
+
 
 class MotionBases(nn.Module):
     """flow3d/params.py:121-180: `rots [K,T,6]`, `transls [K,T,3]`."""

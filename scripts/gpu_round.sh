@@ -10,7 +10,7 @@ python bench.py --steps 30 --warmup 5 2>gpurun_out/${tag}_bench.err | tail -1 | 
 export TMPDIR=/tmp
 R=$PWD
 for cfg in cfg2 cfg5 refdefault; do
-  cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_$cfg -o r1 -- python $R/bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-profile > $R/gpurun_out/${tag}_prof_bench_$cfg.json 2>$R/gpurun_out/${tag}_prof_$cfg.err
+  cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_$cfg -o r1 -- python $R/bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-peaks > $R/gpurun_out/${tag}_prof_bench_$cfg.json 2>$R/gpurun_out/${tag}_prof_$cfg.err
   cd $R
 
   db=$(find gpurun_out/prof_${tag}_$cfg -name "*.db" | head -1)

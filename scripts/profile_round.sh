@@ -10,7 +10,7 @@ mkdir -p gpurun_out
 python bench.py --steps 30 --warmup 5 2>gpurun_out/${tag}_bench.err | tail -1 > gpurun_out/${tag}_bench_cfg2.json
 for cfg in cfg2 cfg3 cfg5 refdefault; do
   steps=10; [ $cfg = cfg5 ] && steps=5
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_$cfg -o r -- python $R/bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline --no-profile > $R/gpurun_out/${tag}_bench_under_rocprof_$cfg.json 2>>$R/gpurun_out/${tag}_prof.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_$cfg -o r -- python $R/bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline --no-profile --no-peaks > $R/gpurun_out/${tag}_bench_under_rocprof_$cfg.json 2>>$R/gpurun_out/${tag}_prof.err)
   db=$(find gpurun_out/${tag}_prof_$cfg -name "*.db" | head -1)
   [ -n "$db" ] && python scripts/rocpd_summary.py $db > gpurun_out/${tag}_kernel_stats_$cfg.csv
   csv=$(find gpurun_out/${tag}_prof_$cfg -name "*kernel_stats.csv" | head -1)
@@ -19,7 +19,7 @@ for cfg in cfg2 cfg3 cfg5 refdefault; do
 done
 # one rank's share of an exposure-sharded cfg2 frame (BASELINE config 4: S / P sub-samples, no collectives) under the same profiler
 for sh in 4 8; do
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_share$sh -o r -- python $R/bench.py --share $sh --steps 10 --warmup 3 --no-cpu-baseline --no-profile > $R/gpurun_out/${tag}_bench_under_rocprof_share$sh.json 2>>$R/gpurun_out/${tag}_prof.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_share$sh -o r -- python $R/bench.py --share $sh --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-peaks > $R/gpurun_out/${tag}_bench_under_rocprof_share$sh.json 2>>$R/gpurun_out/${tag}_prof.err)
   db=$(find gpurun_out/${tag}_prof_share$sh -name "*.db" | head -1)
   [ -n "$db" ] && python scripts/rocpd_summary.py $db > gpurun_out/${tag}_kernel_stats_share$sh.csv
   rm -rf gpurun_out/${tag}_prof_share$sh

@@ -145,3 +145,33 @@ def test_optimizer_without_state_is_left_alone_like_upstream():
     stats["xys_grad_norm_acc"] += 1.0
     control.densify_step(model, stats, opts, control.ControlCfg(), global_step=10)
     assert opts["fg.params.means"].param_groups[0]["params"][0] is old  # trainer.py:1204-1206 returns early
+
+
+def test_spatial_order_step_permutes_every_per_gaussian_tensor_together():
+    """control.spatial_order_step: a pure re-ordering (3-D Morton curve of the means, per Gaussian set - dynamic ones stay first) of
+    parameters, Adam moments and running statistics; neighbours in space become neighbours in memory."""
+    model = _model(n_fg=200, n_bg=150)
+    opts = _optimizers(model)
+    N, nfg = model.num_gaussians, model.num_fg_gaussians
+    stats = control.new_running_stats(N, "cpu")
+    stats["xys_grad_norm_acc"] = torch.arange(N, dtype=torch.float32)  # = the old row index
+    stats["vis_count"] = torch.arange(N)
+    old = {part: {k: v.detach().clone() for k, v in getattr(model, part).params.items()} for part in ("fg", "bg")}
+    mom = {k: o.state[o.param_groups[0]["params"][0]]["exp_avg"].clone() for k, o in opts.items()}
+    plans = control.spatial_order_step(model, stats, opts)
+    assert model.num_fg_gaussians == nfg and model.num_gaussians == N
+    for part, off in (("fg", 0), ("bg", nfg)):
+        perm = plans[part].src.long()
+        n = perm.shape[0]
+        assert sorted(perm.tolist()) == list(range(n))
+        for k, v in getattr(model, part).params.items():
+            assert torch.equal(v.detach(), old[part][k][perm]), (part, k)
+            opt = opts[f"{part}.params.{k}"]
+            assert opt.param_groups[0]["params"][0] is v and torch.equal(opt.state[v]["exp_avg"], mom[f"{part}.params.{k}"][perm])
+        assert torch.equal(stats["xys_grad_norm_acc"][off:off + n], (perm + off).float())
+        assert torch.equal(stats["vis_count"][off:off + n], perm + off)
+        m_old, m_new = old[part]["means"], getattr(model, part).params["means"].detach()
+        step = lambda m: (m[1:] - m[:-1]).norm(dim=-1).mean()
+        assert step(m_new) < 0.6 * step(m_old)  # consecutive rows are now close in space
+    (model.fg.params["means"] ** 2).sum().backward()  # the optimizers still step
+    opts["fg.params.means"].step()
