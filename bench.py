@@ -94,10 +94,10 @@ def parse():
                          "process-group set-up, the sharded step's collectives, the graph-capture fallback agreement, max-over-ranks "
                          "timing, ONE JSON line - with the render replaced by a synthetic differentiable image.  Measures nothing.")
     ap.add_argument("--no-peaks", action="store_true", help="skip d4gs_measure_peaks (profiler passes: keeps its kernels out of the trace)")
-    ap.add_argument("--spatial-order", action="store_true",
+    ap.add_argument("--spatial-order", nargs="?", const="view", default=None, choices=["view", "3d"],
                     help="secondary measurement: the same Gaussians in the order deblur4dgs_amd.control.spatial_order_step leaves them in "
-                         "(3-D Morton curve of the means, per set) instead of the generator's random order; the headline keeps the "
-                         "random order")
+                         "(Morton curve over the camera's image plane, per set; `3d`: over world space) instead of the generator's random "
+                         "order; the headline keeps the random order")
     ap.add_argument("--share", type=int, default=1, metavar="P",
                     help="diagnostic (not the headline): render only rank 0's share {s : s %% P == 0} of the exposure sub-samples, no "
                          "collectives - the device work ONE rank of an exposure-sharded frame at world size P executes "
@@ -448,10 +448,11 @@ def main():
 
             with torch.no_grad():
                 m = leaves["means"].detach()
-                perm = torch.cat([morton_permutation(m[:G]), G + morton_permutation(m[G:])]) if 0 < G < N else morton_permutation(m)
+                vm = None if args.spatial_order == "3d" else leaves["viewmat"].detach()
+                perm = torch.cat([morton_permutation(m[:G], vm), G + morton_permutation(m[G:], vm)]) if 0 < G < N else morton_permutation(m, vm)
                 for k in ("means", "quats", "scales", "opacities", "colors", "motion_coefs"):
                     if k in leaves:
-                        pk = perm if leaves[k].shape[0] == N else morton_permutation(m[:G])
+                        pk = perm if leaves[k].shape[0] == N else morton_permutation(m[:G], vm)
                         leaves[k] = leaves[k].detach()[pk].clone().requires_grad_()
         if args.share > 1 and not use_dist:
             for k in ("times", "RTs"):
@@ -633,7 +634,7 @@ def main():
         "instances_per_s": value * S,
     }
     if args.spatial_order:
-        out["config"]["workload"] += "; Gaussians in 3-D Morton order (control.spatial_order_step)"
+        out["config"]["workload"] += f"; Gaussians in Morton order ({args.spatial_order}; control.spatial_order_step)"
     if args.share > 1:
         out["metric"] = f"DIAGNOSTIC rank-0 share of {name} at world size {args.share} (no collectives), Gaussians / t"
         out["config"]["workload"] += f"; ONLY sub-samples s % {args.share} == 0 rendered (--share)"

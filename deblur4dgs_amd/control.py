@@ -187,32 +187,50 @@ def cull_step(model, running_stats: dict, optimizers: dict, cfg: ControlCfg, glo
     return sum(p.n_in - p.n_keep for p in plans.values())
 
 
-def morton_permutation(means: torch.Tensor, bits: int = 10) -> torch.Tensor:
-    """Permutation that sorts the rows of `means` [n, 3] by the 3-D Morton code of their position inside the bounding box
-    (`bits` per axis)."""
-    lo, hi = means.amin(0), means.amax(0)
-    q = ((means - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).round().long().clamp_(0, (1 << bits) - 1)
+def morton_permutation(means: torch.Tensor, viewmat: torch.Tensor | None = None, bits: int = 10) -> torch.Tensor:
+    """Permutation that sorts the rows of `means` [n, 3] along a Morton curve.  With `viewmat` [4, 4] (world -> camera): the 2-D
+    curve over the image-plane position (x / z, y / z) seen from that camera - depth is deliberately NOT part of the key; without:
+    the 3-D curve over the bounding box.  `bits` per axis."""
+    if means.shape[0] == 0:
+        return torch.zeros(0, dtype=torch.int64, device=means.device)
+    if viewmat is not None:
+        pc = means @ viewmat[:3, :3].T.to(means) + viewmat[:3, 3].to(means)
+        z = pc[:, 2:3].clamp_min(1e-6)
+        pts = pc[:, :2] / z
+        pts = pts.clamp(pts.median(0).values - 4 * pts.std(0), pts.median(0).values + 4 * pts.std(0))  # far off-screen outliers
+    else:
+        pts = means
+    lo, hi = pts.amin(0), pts.amax(0)
+    q = ((pts - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).round().long().clamp_(0, (1 << bits) - 1)
     code = torch.zeros(means.shape[0], dtype=torch.int64, device=means.device)
+    nd = pts.shape[1]
     for b in range(bits):
-        for a in range(3):
-            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        for a in range(nd):
+            code |= ((q[:, a] >> b) & 1) << (nd * b + a)
     return torch.argsort(code, stable=True)
 
 
 @torch.no_grad()
-def spatial_order_step(model, running_stats: dict | None, optimizers: dict, only_fg: bool = False):
-    """Re-order the Gaussians of each set (fg, bg - the dynamic ones stay first) along a 3-D Morton curve of their means: same
-    scene, same image (the composite orders by depth, ties by index: tests/test_gpu_control.py), but Gaussians that are
-    neighbours on screen become neighbours in memory - the binning pass writes longer runs per (block, tile list) and the
-    per-instance gathers hit the L2.  Measured (bench.py --spatial-order): cfg5 9.67 -> 8.95 ms (k_emit 1 125 ->
-    717 us, k_gather 903 -> 667), cfg3 3.67 -> 3.55, cfg2 1.424 -> 1.399.  No reference counterpart: the reference's order is whatever
+def spatial_order_step(model, running_stats: dict | None, optimizers: dict, only_fg: bool = False, viewmat="first"):
+    """Re-order the Gaussians of each set (fg, bg - the dynamic ones stay first) along a Morton curve: same scene, same image (the
+    composite orders by depth, ties by index: tests/test_gpu_control.py), but Gaussians that are neighbours on screen become
+    neighbours in memory - the binning pass writes longer runs per (block, tile list) and the per-instance gathers hit the L2.
+    `viewmat`: the camera whose image plane carries the curve - "first" = the model's first training camera (forward-facing
+    captures like the reference's stereo-blur scenes: every training view sees roughly that layout), a [4, 4] tensor, or None = the
+    3-D curve over world space.  Prefer a camera: keyed on the image plane only, a run of neighbouring Gaussians mixes near (large
+    footprint) and far ones, whereas the 3-D curve packs the near ones together and a wave of `k_gather` - one lane per Gaussian,
+    the wave streams the rows of its 64 - then owns 64 long row spans (measured, bench.py --spatial-order: cfg5 9.63 -> 8.95 ms with
+    the camera's curve, k_emit 1 124 -> 717 us and k_gather 909 -> 667; with the 3-D curve k_emit 693 but k_gather 1 021; cfg2 with 4x
+    larger splats: k_gather 152 -> 1 029 us under the 3-D curve).  No reference counterpart: the reference's order is whatever
     initialisation and densification (kept, duplicated, split rows: flow3d/params.py:86-118) left; meant to ride on the control
     steps that re-write every row anyway (every `ControlCfg.control_every` steps).  Parameters, Adam moments and running statistics
     move together, like in `densify_step` / `cull_step`."""
     nfg = model.num_fg_gaussians
+    if isinstance(viewmat, str):
+        viewmat = model.w2cs[0] if viewmat == "first" else None
     plans = {}
     for name, part in _parts(model, only_fg):
-        plans[name] = plan = RowPlan.from_permutation(morton_permutation(part.params["means"].detach()))
+        plans[name] = plan = RowPlan.from_permutation(morton_permutation(part.params["means"].detach(), viewmat))
         for pname, p_new in part.reorder_params(plan).items():
             opt = optimizers.get(f"{name}.params.{pname}")
             if opt is not None:

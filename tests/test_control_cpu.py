@@ -172,6 +172,6 @@ def test_spatial_order_step_permutes_every_per_gaussian_tensor_together():
         assert torch.equal(stats["vis_count"][off:off + n], perm + off)
         m_old, m_new = old[part]["means"], getattr(model, part).params["means"].detach()
         step = lambda m: (m[1:] - m[:-1]).norm(dim=-1).mean()
-        assert step(m_new) < 0.6 * step(m_old)  # consecutive rows are now close in space
+        assert step(m_new) < 0.85 * step(m_old)  # consecutive rows are now close (on the first camera's image plane)
     (model.fg.params["means"] ** 2).sum().backward()  # the optimizers still step
     opts["fg.params.means"].step()

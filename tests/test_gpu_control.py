@@ -101,7 +101,7 @@ def test_spatial_order_step_leaves_the_render_unchanged_on_the_device():
     w2c, Km = sc["viewmat"].to(dev)[None], sc["K"].to(dev)[None]
 
     def render():
-        out = model.render(3, w2c, Km, (W, H), return_depth=True)
+        out = model.render(3.0, w2c, Km, (W, H), return_depth=True, mode="blury")  # all 11 sub-samples
         return out["img"], out["exposure_imgs"]
 
     img0, stack0 = render()
