@@ -417,7 +417,7 @@ def main():
         """SURVEY 8d / BASELINE.md section 4: the ceilings are MEASURED on this box, before the timed region - a ~1 GiB
         device-to-device stream copy and an FMA issue loop (d4gs_measure_peaks, csrc/peaks.hip; ~30 ms of device time)."""
         try:
-            scratch = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            scratch = torch.empty(1 << 31, dtype=torch.uint8, device=dev)  # 2 x 1 GiB: far beyond the 256 MB MALL
             scratch.zero_()
             out = (C.c_double * 4)()
             rc = lib.d4gs_measure_peaks(C.c_void_p(scratch.data_ptr()), C.c_size_t(scratch.numel()), out,
@@ -429,8 +429,8 @@ def main():
                 return None
             return {"hbm_stream_copy_gbs": out[0], "fp32_pk_fma_tflops": out[1], "fp32_fma_tflops": out[2],
                     "copy_bytes_per_launch": out[3],
-                    "how": "d4gs_measure_peaks on this GPU right before the timed region: device-to-device float4 stream copy "
-                           "(read + write bytes / best of 8 launches), v_pk_fma_f32 and v_fma_f32 issue loops at 8 waves per SIMD "
+                    "how": "d4gs_measure_peaks on this GPU right before the timed region: device-to-device float4 stream copy of 1 GiB "
+                           "(non-temporal, 8 loads in flight per lane, 256 workgroups per CU; read + write bytes / best of 8 launches), v_pk_fma_f32 and v_fma_f32 issue loops at 8 waves per SIMD "
                            "(16 independent chains per lane, best of 5)"}
         except Exception as e:  # the ceilings are context, not the measurement: never take the bench line down
             sys.stderr.write(f"d4gs_measure_peaks failed: {e!r}\n")

@@ -7,16 +7,19 @@
 
 namespace {
 
-// device-to-device stream copy, 16 bytes per lane and access, grid-stride over a grid that fills the machine
+// device-to-device stream copy, 16 bytes per lane and access, grid-stride.  Shape picked by scripts/microbench/stream_copy.hip
+// (profiles/r04_x_stream_copy.txt): non-temporal accesses, 8 loads in flight per lane, 256 workgroups per CU - 5.9 TB/s on 2 x 512 MiB,
+// 5.3 TB/s on 2 x 2 GiB (the 256 MB MALL no longer helps), against 4.6 - 5.1 for plain accesses or grids of 8 - 16 workgroups per CU
 typedef float v4f __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_peak_copy(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t n4) {
   const size_t stride = (size_t)gridDim.x * 256;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
-    const v4f a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-    const v4f c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-    __builtin_nontemporal_store(a, dst + i), __builtin_nontemporal_store(b, dst + i + stride);
-    __builtin_nontemporal_store(c, dst + i + 2 * stride), __builtin_nontemporal_store(d, dst + i + 3 * stride);
+  for (; i + 7 * stride < n4; i += 8 * stride) {  // eight independent 16-byte loads in flight per lane
+    v4f r[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) r[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; u++) __builtin_nontemporal_store(r[u], dst + i + u * stride);
   }
   for (; i < n4; i += stride) dst[i] = src[i];
 }
@@ -90,7 +93,7 @@ extern "C" int d4gs_measure_peaks(void *scratch, size_t scratch_bytes, double *o
   float best_copy = 1e30f;
   for (int rep = 0; rep < 10; rep++) {
     (void)hipEventRecord(t.a, stream);
-    hipLaunchKernelGGL(k_peak_copy, dim3(cus * 16), dim3(256), 0, stream, src, dst, n4);
+    hipLaunchKernelGGL(k_peak_copy, dim3(cus * 256), dim3(256), 0, stream, src, dst, n4);
     (void)hipEventRecord(t.b, stream);
     if (hipEventSynchronize(t.b) != hipSuccess) break;
     float ms = 0.f;
