@@ -93,6 +93,9 @@ def parse():
                     help="run the N > 1 control flow of this script on CPU tensors over gloo (tests/test_parallel_gloo.py): "
                          "process-group set-up, the sharded step's collectives, the graph-capture fallback agreement, max-over-ranks "
                          "timing, ONE JSON line - with the render replaced by a synthetic differentiable image.  Measures nothing.")
+    ap.add_argument("--lazy-sort", action="store_true",
+                    help="secondary measurement: D4GS_LAZY_SORT (near / far partition of the tile lists, far parts sorted only for tiles "
+                         "that did not saturate in the near part; for occluded / large-footprint scenes, e.g. --scale-mul 4)")
     ap.add_argument("--no-peaks", action="store_true", help="skip d4gs_measure_peaks (profiler passes: keeps its kernels out of the trace)")
     ap.add_argument("--spatial-order", nargs="?", const="view", default=None, choices=["view", "3d"],
                     help="secondary measurement: the same Gaussians in the order deblur4dgs_amd.control.spatial_order_step leaves them in "
@@ -476,7 +479,8 @@ def main():
                 res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                       leaves["colors"], 3, leaves.get("motion_coefs"), leaves.get("rots"),
                                       leaves.get("transls"), leaves.get("times"), leaves["RTs"], leaves["viewmat"], d["K"],
-                                      W, H, background=bg, return_depth=True, deferred_size_check=mode_flag["deferred"], fused=mode_flag["fused"])
+                                      W, H, background=bg, return_depth=True, deferred_size_check=mode_flag["deferred"], fused=mode_flag["fused"],
+                                      lazy_sort=True if args.lazy_sort else None)
                 loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
                 loss.backward()
                 last["st"] = res["state"]
@@ -517,7 +521,8 @@ def main():
                 res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                       leaves["colors"], 3, leaves.get("motion_coefs"), leaves.get("rots"),
                                       leaves.get("transls"), leaves.get("times"), leaves["RTs"], leaves["viewmat"], d["K"],
-                                      W, H, background=bg, return_depth=True, deferred_size_check=True, fused=mode_flag["fused"])
+                                      W, H, background=bg, return_depth=True, deferred_size_check=True, fused=mode_flag["fused"],
+                                      lazy_sort=True if args.lazy_sort else None)
                 loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
                 loss.backward()
                 return res["state"]
@@ -633,6 +638,8 @@ def main():
                     if not views_primary else f"views sharded x{world} (data parallel), RCCL gradient all-reduce")},
         "instances_per_s": value * S,
     }
+    if args.lazy_sort:
+        out["config"]["workload"] += "; D4GS_LAZY_SORT"
     if args.spatial_order:
         out["config"]["workload"] += f"; Gaussians in Morton order ({args.spatial_order}; control.spatial_order_step)"
     if args.share > 1:

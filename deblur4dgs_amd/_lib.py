@@ -30,11 +30,12 @@ class ProjIn(C.Structure):
 
 class ProjOut(C.Structure):
     _fields_ = [(n, F) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects", "tiles_touched",
-                                 "isect_offsets", "tile_ranks", "tile_counts", "tile_offsets", "n_isect", "scan_ws")]
+                                 "isect_offsets", "lazy_ws", "tile_counts", "tile_offsets", "n_isect", "scan_ws")]
 
 
 class Isect(C.Structure):
-    _fields_ = [("n_isect", C.c_int64), ("max_tile_count", C.c_int64)] + [(n, F) for n in ("keys", "gid_of_emit", "sorted_gid", "sorted_emit")]
+    _fields_ = [("n_isect", C.c_int64), ("max_tile_count", C.c_int64), ("near_target", C.c_int64)] + \
+               [(n, F) for n in ("keys", "gid_of_emit", "sorted_gid", "sorted_emit")]
 
 
 class Raster(C.Structure):
@@ -51,7 +52,7 @@ class Sizes(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects",
                                          "tiles_touched", "isect_offsets", "tile_counts", "tile_offsets", "n_isect",
                                          "scan_ws", "render_colors", "render_alphas", "last_ids", "final_T",
-                                         "isect_grad_row", "bwd_partials", "seg_state")] + \
+                                         "isect_grad_row", "bwd_partials", "seg_state", "lazy_ws")] + \
                [(n, C.c_int32) for n in ("tiles_x", "tiles_y", "channels")]
 
 
@@ -79,7 +80,7 @@ class ShardBlend(C.Structure):
 
 class FrameIO(C.Structure):
     _fields_ = [(n, F) for n in ("blended", "acc", "renders", "alphas", "means2d", "radii", "n_isect", "background")] + \
-               [("policy", C.POINTER(C.c_int32))]
+               [("policy", C.POINTER(C.c_int32)), ("near_target", C.c_int64)]
 
 
 class FrameGrads(C.Structure):
@@ -92,7 +93,7 @@ class Poses(C.Structure):
     _fields_ = [("means", F), ("quats", F), ("transforms", F), ("g_major", C.c_int32)]
 
 
-RAW_PARAMS, RAW_COLORS, EXACT_CULL = 1, 2, 4
+RAW_PARAMS, RAW_COLORS, EXACT_CULL, LAZY_SORT = 1, 2, 4, 8
 DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
 ROWS_AUTO, ROWS_DENSE, ROWS_SPARSE = 0, 1, 2
 TILE = 16

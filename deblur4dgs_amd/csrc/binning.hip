@@ -30,6 +30,7 @@ struct EmitArgs {
   const int64_t *n_dev;  // device {total, longest list}: the launch is a no-op when they exceed what the caller sized
   int64_t cap, max_hint;
   int use_lds;
+  LazyWs lazy;  // D4GS_LAZY_SORT instantiation: near / far partition of every list (common.h)
 };
 
 // D4gsIsect.n_isect is a CAPACITY: the host may size the lists from a guess and look at the real count afterwards.
@@ -47,19 +48,28 @@ __device__ __forceinline__ bool over_capacity(const int64_t *n_dev, int64_t cap,
 // has to be carried from the counting pass, splats of any footprint take the same path, and the 8-byte key stores
 // of a block fall into short contiguous runs.  Tile grids too big for the LDS histogram use global cursors.
 constexpr int EMIT_THREADS = 1024;
-template <int EMIT_PER_THREAD>  // = d4gs_chunk_per_thread(dims), like k_count_tiles
+// LAZY (D4GS_LAZY_SORT): every tile has TWO bins - the keys of the depth buckets up to the tile's pivot go to the front of its list
+// (the near part, lazy.near[t] keys), the others behind them; k_tile_sort orders the two parts separately, the far one on demand.
+template <int EMIT_PER_THREAD, bool LAZY>  // EMIT_PER_THREAD = d4gs_chunk_per_thread(dims), like k_count_tiles
 __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
-  extern __shared__ int bins[];  // [tiles]
+  extern __shared__ int bins[];  // [tiles] (LAZY: [tiles][2])
   if (over_capacity(a.n_dev, a.cap, a.max_hint)) return;
   const int tiles = a.tw * a.th, tid = threadIdx.x;
   const int s = blockIdx.x % a.d.S, chunk = blockIdx.x / a.d.S;
   const int tbase = s * tiles, n_tiles_all = a.d.S * tiles;
   const bool lds = a.use_lds;
+  constexpr int NP = LAZY ? 2 : 1;
   if (lds) {
-    for (int z = tid; z < tiles; z += EMIT_THREADS) bins[z] = 0;
+    for (int z = tid; z < NP * tiles; z += EMIT_THREADS) bins[z] = 0;
     __syncthreads();
   }
-  int cnt[EMIT_PER_THREAD], rx[EMIT_PER_THREAD], ry[EMIT_PER_THREAD];
+  const uint32_t zlo = LAZY ? ~a.lazy.zr[2 * s] : 0u, zhi = LAZY ? a.lazy.zr[2 * s + 1] : 0u;
+  int *piv = bins + NP * tiles;  // LAZY: the sub-sample's pivots, staged once per block (one read per key otherwise)
+  if (LAZY) {
+    for (int z = tid; z < tiles; z += EMIT_THREADS) piv[z] = a.lazy.pivot[tbase + z];
+    __syncthreads();
+  }
+  int cnt[EMIT_PER_THREAD], rx[EMIT_PER_THREAD], ry[EMIT_PER_THREAD], bkq[EMIT_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < EMIT_PER_THREAD; q++) {
     const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
@@ -70,19 +80,27 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
       if (cnt[q] > 0) {
         const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
         rx[q] = rc.x, ry[q] = rc.y;
+        bkq[q] = LAZY ? d4gs_depth_bucket(a.depths[i], zlo, zhi, a.lazy.nb) : 0;
         if (lds) {
           const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
           for (int ty = y0; ty < y1; ty++)
-            for (int tx = x0; tx < x1; tx++) atomicAdd(&bins[ty * a.tw + tx], 1);
+            for (int tx = x0; tx < x1; tx++) {
+              const int t = ty * a.tw + tx;
+              if (LAZY) atomicAdd(&bins[2 * t + (bkq[q] > piv[t] ? 1 : 0)], 1);
+              else atomicAdd(&bins[t], 1);
+            }
         }
       }
     }
   }
   if (lds) {
     __syncthreads();
-    for (int z = tid; z < tiles; z += EMIT_THREADS) {
+    for (int z = tid; z < NP * tiles; z += EMIT_THREADS) {
       const int c = bins[z];
-      if (c > 0) bins[z] = a.tile_offsets[tbase + z] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + z, c);
+      if (LAZY) {
+        const int t = tbase + (z >> 1), far = z & 1;
+        if (c > 0) bins[z] = a.tile_offsets[t] + (far ? a.lazy.near[t] : 0) + atomicAdd(a.lazy.cur + 2 * t + far, c);
+      } else if (c > 0) bins[z] = a.tile_offsets[tbase + z] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + z, c);
     }
     __syncthreads();
   }
@@ -128,8 +146,9 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
     for (int ty = y0; ty < y1; ty++)
       for (int tx = x0; tx < x1; tx++) {
         const int t = ty * a.tw + tx;
-        const int slot = lds ? atomicAdd(&bins[t], 1)
-                             : a.tile_offsets[tbase + t] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + t, 1);
+        const int slot = LAZY ? atomicAdd(&bins[2 * t + (bkq[q] > piv[t] ? 1 : 0)], 1)
+                         : lds ? atomicAdd(&bins[t], 1)
+                               : a.tile_offsets[tbase + t] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + t, 1);
         a.keys[slot] = hi | e;
         a.gid_of_emit[e] = g;
         e++;
@@ -315,7 +334,21 @@ struct SortArgs {
   const int64_t *n_dev;
   int64_t n_cap, max_hint;
   int n_lists;
+  // D4GS_LAZY_SORT: pass 1 sorts the near part [base, base + near[t]) of every list, pass 2 the far part of the lists whose tile was
+  // flagged by the forward composite (it did not saturate within the near part); pass 0: whole lists
+  const int32_t *lazy_near, *lazy_flag;
+  int pass;
 };
+// -> false: nothing to sort for this list in this pass
+__device__ __forceinline__ bool lazy_range(const SortArgs &a, int t, int &base, int &n) {
+  if (a.pass == 1) n = min(n, a.lazy_near[t]);
+  else if (a.pass == 2) {
+    const int nn = a.lazy_near[t];
+    if (nn >= n || !a.lazy_flag[t]) return false;
+    base += nn, n -= nn;
+  }
+  return true;
+}
 
 // lists of up to 512 keys: one WAVE per list, straight from global memory into registers and back - no LDS, no barrier
 template <int NV>
@@ -340,8 +373,9 @@ __global__ void __launch_bounds__(256) k_tile_sort_w(const SortArgs a) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= a.n_lists) return;
-  const int base = a.tile_offsets[t];
-  const int n = a.tile_offsets[t + 1] - base;
+  int base = a.tile_offsets[t];
+  int n = a.tile_offsets[t + 1] - base;
+  if (a.pass && !lazy_range(a, t, base, n)) return;
   if (n <= 0 || n > CHUNK) return;
   if (n <= 64) wave_sort_list<1>(a, base, n, lane);
   else if (n <= 128) wave_sort_list<2>(a, base, n, lane);
@@ -353,8 +387,9 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const SortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
   if (over_capacity(a.n_dev, a.n_cap, a.max_hint)) return;
   const int t = blockIdx.x;
-  const int base = a.tile_offsets[t];
-  const int n = a.tile_offsets[t + 1] - base;
+  int base = a.tile_offsets[t];
+  int n = a.tile_offsets[t + 1] - base;
+  if (a.pass && !lazy_range(a, t, base, n)) return;
   if (n <= a.lo || (a.cap >= 0 && n > a.cap)) return;
   if (n <= CHUNK) {  // (only when lo == 0, the first class of a scene that also has longer lists: one launch for both kinds)
     if (threadIdx.x < 64) {  // one wave sorts the list in registers, exactly as k_tile_sort_w would
@@ -388,6 +423,41 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const SortArgs a) {
   }
 }
 
+
+// Size classes, one launch each (a workgroup exits at once if its list is not in the class): lists of up to 512 keys take
+// one wave each, in registers (k_tile_sort_w); beyond that the LDS a workgroup reserves and its width follow the list
+// length - 16 KB / 256 lanes up to 2048 keys (8+ workgroups per CU) ... 128 KB / 1024 lanes up to 16384 keys, anything longer in
+// global memory.  (Round 1 had only the 16 KB and 128 KB classes: a scene whose lists run to ~4 k keys sorted them one workgroup
+// of 4 waves per CU - 1.54 ms on cfg2 with 4x larger splats.)  pass: 0 whole lists, 1 / 2 the near / flagged far parts
+// (D4GS_LAZY_SORT).
+int launch_sorts(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, int pass, hipStream_t stream) {
+  const int tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE, th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
+  const int n_tiles = dims->S * tw * th;
+  LazyWs lw{};
+  if (pass) lw = d4gs_lazy_carve(proj->lazy_ws, dims->S, tw * th);
+  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
+  (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+  const int64_t longest = isect->max_tile_count > 0 ? isect->max_tile_count : isect->n_isect;
+  // Lists of up to 512 keys: one wave each, in registers, four lists per workgroup (k_tile_sort_w) - unless the lists average
+  // well above 512 keys (cfg2: 935): then that launch would find (almost) nothing to do and the few short lists ride in the first
+  // LDS class's launch instead (wave 0 of their workgroup, same register sort): one launch less, 5 - 7 us per frame on cfg2.
+  const bool merge_short = pass == 0 && longest > CHUNK && isect->n_isect >= (int64_t)768 * n_tiles;  // (capacity ~ 1.25 x the count)
+  if (!merge_short) {
+    SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
+               0, CHUNK, proj->n_isect, isect->n_isect, isect->max_tile_count, n_tiles, lw.near, lw.flag, pass};
+    D4GS_LAUNCH("k_tile_sort_w", k_tile_sort_w, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, s);
+  }
+  const int classes[6][3] = {{merge_short ? 0 : CHUNK, 2048, 256}, {2048, 4096, 512}, {4096, 8192, 1024}, {8192, 16384, 1024}, {16384, -1, 1024}};
+  for (int c = 0; c < 5; c++) {
+    if (longest <= classes[c][0]) break;  // no list is that long
+    SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
+               classes[c][0], classes[c][1], proj->n_isect, isect->n_isect, isect->max_tile_count, n_tiles, lw.near, lw.flag, pass};
+    const size_t lds = classes[c][1] > 0 ? (size_t)classes[c][1] * 8 : 0;
+    D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(classes[c][2]), lds, stream, s);
+  }
+  return d4gs_check_launch("k_tile_sort");
+}
+
 }  // namespace
 
 int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream) {
@@ -417,40 +487,36 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   }
   const size_t bins_bytes = sizeof(int) * (size_t)e.tw * e.th;
   e.use_lds = bins_bytes <= 64 * 1024;
-  if (pt == 1)
-    D4GS_LAUNCH("k_emit", k_emit<1>, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS),
-                e.use_lds ? bins_bytes : 0, stream, e);
-  else
-    D4GS_LAUNCH("k_emit", k_emit<4>, dim3((unsigned)(((dims->N + per_block - 1) / per_block) * dims->S)), dim3(EMIT_THREADS),
-                e.use_lds ? bins_bytes : 0, stream, e);
+  const bool lazy = d4gs_lazy_on(dims, proj);
+  e.lazy = LazyWs{};
+  if (lazy) {  // every tile's near / far pivot first (the caller's near_target is known here, not in d4gs_project_fwd)
+    e.lazy = d4gs_lazy_carve(proj->lazy_ws, dims->S, e.tw * e.th);
+    int rc = d4gs_lazy_pivot_launch(dims, proj, isect->near_target, stream);
+    if (rc) return rc;
+  }
+  const unsigned eblocks = (unsigned)(((dims->N + per_block - 1) / per_block) * dims->S);
+  const size_t ebytes = e.use_lds ? bins_bytes * (lazy ? 3 : 1) : 0;
+#define D4GS_EMIT(PT_, LZ_)                                                                                               \
+  do {                                                                                                                    \
+    if (ebytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_emit<PT_, LZ_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); \
+    D4GS_LAUNCH("k_emit", (k_emit<PT_, LZ_>), dim3(eblocks), dim3(EMIT_THREADS), ebytes, stream, e);                     \
+  } while (0)
+  if (pt == 1 && lazy) D4GS_EMIT(1, true);
+  else if (pt == 1) D4GS_EMIT(1, false);
+  else if (lazy) D4GS_EMIT(4, true);
+  else D4GS_EMIT(4, false);
+#undef D4GS_EMIT
   int rc = d4gs_check_launch("k_emit");
   if (rc) return rc;
-  const int n_tiles = dims->S * e.tw * e.th;
-  // Size classes, one launch each (a workgroup exits at once if its list is not in the class): lists of up to 512 keys take
-  // one wave each, in registers (k_tile_sort_w); beyond that the LDS a workgroup reserves and its width follow the list
-  // length - 16 KB / 256 lanes up to 2048 keys (8+ workgroups per CU) ...
-  // 128 KB / 1024 lanes up to 16384 keys, anything longer in global memory.  (Round 1 had only the 16 KB and 128 KB
-  // classes: a scene whose lists run to ~4 k keys sorted them one workgroup of 4 waves per CU - 1.54 ms on cfg2 with
-  // 4x larger splats.)
-  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
-  (void)hipFuncSetAttribute((const void *)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-  const int64_t longest = isect->max_tile_count > 0 ? isect->max_tile_count : isect->n_isect;
-  // Lists of up to 512 keys: one wave each, in registers, four lists per workgroup (k_tile_sort_w) - unless the lists average
-  // well above 512 keys (cfg2: 935): then that launch would find (almost) nothing to do and the few short lists ride in the first
-  // LDS class's launch instead (wave 0 of their workgroup, same register sort): one launch less, 5 - 7 us per frame on cfg2.
-  const bool merge_short = longest > CHUNK && isect->n_isect >= (int64_t)768 * n_tiles;  // (capacity ~ 1.25 x the count)
-  if (!merge_short) {
-    SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
-               0, CHUNK, proj->n_isect, isect->n_isect, isect->max_tile_count, n_tiles};
-    D4GS_LAUNCH("k_tile_sort_w", k_tile_sort_w, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, s);
-  }
-  const int classes[6][3] = {{merge_short ? 0 : CHUNK, 2048, 256}, {2048, 4096, 512}, {4096, 8192, 1024}, {8192, 16384, 1024}, {16384, -1, 1024}};
-  for (int c = 0; c < 5; c++) {
-    if (longest <= classes[c][0]) break;  // no list is that long
-    SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
-               classes[c][0], classes[c][1], proj->n_isect, isect->n_isect, isect->max_tile_count, n_tiles};
-    const size_t lds = classes[c][1] > 0 ? (size_t)classes[c][1] * 8 : 0;
-    D4GS_LAUNCH("k_tile_sort", k_tile_sort, dim3(n_tiles), dim3(classes[c][2]), lds, stream, s);
-  }
-  return d4gs_check_launch("k_tile_sort");
+  return launch_sorts(dims, proj, isect, lazy ? 1 : 0, stream);
 }
+
+// D4GS_LAZY_SORT, second half (called by d4gs_raster_fwd between its two composite passes): the far parts of the lists whose tile
+// the first pass flagged are sorted.  The far parts of the other lists - rows behind their tile's last contributor - are left as
+// emitted: nothing composites or replays them, and the backward of a lazy render always takes SPARSE gradient rows (raster_bwd.hip),
+// which never touches a dead row (copying their emission indices for the dense zero-fill cost 176 us on cfg2 with 4x splats -
+// more than the sort it saved).
+int d4gs_lazy_far_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream) {
+  return launch_sorts(dims, proj, isect, 2, stream);
+}
+

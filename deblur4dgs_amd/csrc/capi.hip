@@ -146,6 +146,7 @@ int d4gs_query_sizes(const D4gsDims *d, D4gsSizes *z) {
   z->isect_grad_row = 6 + nch;
   z->bwd_partials = (int64_t)d4gs_bwd_partials_elems(d);
   z->seg_state = d4gs_seg_state_elems(d);
+  z->lazy_ws = d4gs_lazy_ws_elems((int)S, (int)(tw * th));
   z->tiles_x = (int32_t)tw, z->tiles_y = (int32_t)th, z->channels = (int32_t)nch;
   return D4GS_OK;
 }

@@ -326,6 +326,41 @@ int64_t d4gs_seg_state_elems(const D4gsDims *d);
 // do the composite kernels of this launch use segments?  (the forward writes the boundary states, the backward replays by segment)
 bool d4gs_seg_on(const D4gsDims *d, const D4gsIsect *isect, const D4gsRaster *r);
 
+// ---- D4GS_LAZY_SORT: near / far partition of the tile lists (include/d4gs.h) ----------------------------------------
+// lazy_ws (int32): hist [T][NB] (tile, depth bucket) counts | near [T] keys in the near part | pivot [T] last near bucket |
+// cur [T][2] near / far slot cursors | flag [T] 1 = the tile did not saturate within its near part | zr [S][2] depth range of the
+// sub-sample as float bits (zr[0] = ~min bits, zr[1] = max bits: both grow under atomicMax from a zeroed buffer).  T = S * tiles.
+struct LazyWs {
+  int32_t *hist, *near, *pivot, *cur, *flag;
+  uint32_t *zr;
+  int nb;
+};
+__host__ __device__ __forceinline__ int d4gs_lazy_buckets(int tiles_per_subsample) { return tiles_per_subsample <= 2048 ? 8 : 4; }
+__host__ __device__ __forceinline__ int64_t d4gs_lazy_ws_elems(int S, int tiles_per_subsample) {
+  const int64_t T = (int64_t)S * tiles_per_subsample;
+  return T * (d4gs_lazy_buckets(tiles_per_subsample) + 5) + 2 * (int64_t)S + 8;
+}
+__host__ __device__ __forceinline__ LazyWs d4gs_lazy_carve(int32_t *ws, int S, int tiles_per_subsample) {
+  LazyWs w;
+  const int64_t T = (int64_t)S * tiles_per_subsample;
+  w.nb = d4gs_lazy_buckets(tiles_per_subsample);
+  w.hist = ws, w.near = w.hist + T * w.nb, w.pivot = w.near + T, w.cur = w.pivot + T, w.flag = w.cur + 2 * T;
+  w.zr = reinterpret_cast<uint32_t *>(w.flag + T);
+  return w;
+}
+// depth bucket of an instance: piecewise linear in the float's bit pattern (monotone in the depth, no transcendental, the same
+// integer arithmetic wherever it is evaluated) between the sub-sample's smallest and largest visible depth
+__device__ __forceinline__ int d4gs_depth_bucket(float depth, uint32_t zmin_bits, uint32_t zmax_bits, int nb) {
+  const uint32_t b = __float_as_uint(depth);
+  const uint64_t span = (uint64_t)(zmax_bits - zmin_bits) + 1u;
+  const uint64_t off = b > zmin_bits ? (uint64_t)(b - zmin_bits) : 0u;
+  const int k = (int)((off * (uint64_t)nb) / span);
+  return k < nb ? k : nb - 1;
+}
+
+bool d4gs_lazy_on(const D4gsDims *d, const D4gsProjOut *out);
+int d4gs_lazy_pivot_launch(const D4gsDims *d, const D4gsProjOut *out, int64_t near_target, hipStream_t stream);
+int d4gs_lazy_far_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream);
 // Instances per lane of the 1024-lane blocks of k_count_tiles / k_emit (their chunks must agree): 4 - or 1 when 4 would leave
 // fewer blocks than CUs (one or two sub-samples of a few 100 k Gaussians: S = 1, N = 300 k gave 74 blocks for 256 CUs).
 int d4gs_chunk_per_thread(const D4gsDims *d);

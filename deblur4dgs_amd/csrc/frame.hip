@@ -53,6 +53,7 @@ FrameBufs carve(const D4gsDims *d, int64_t cap, void *ws) {
   b.proj.tile_rects = c.take<int32_t>(z.tile_rects), b.proj.tiles_touched = c.take<int32_t>(z.tiles_touched);
   b.proj.isect_offsets = c.take<int32_t>(z.isect_offsets), b.proj.tile_counts = c.take<int32_t>(z.tile_counts);
   b.proj.tile_offsets = c.take<int32_t>(z.tile_offsets), b.proj.scan_ws = c.take<int32_t>(z.scan_ws);
+  b.proj.lazy_ws = (d->flags & D4GS_LAZY_SORT) ? c.take<int32_t>(z.lazy_ws) : nullptr;
   b.isect.keys = c.take<uint64_t>(m), b.isect.gid_of_emit = c.take<int32_t>(m);
   b.isect.sorted_gid = c.take<int32_t>(m), b.isect.sorted_emit = c.take<int32_t>(m);
   b.raster.last_ids = c.take<int32_t>(z.last_ids), b.raster.final_T = c.take<float>(z.final_T);
@@ -92,8 +93,8 @@ int check_frame(const char *who, const D4gsDims *d, const D4gsProjIn *in, const 
 }
 
 void bind_io(FrameBufs &b, const D4gsFrameIO *io, int64_t cap, int64_t max_hint) {
-  b.proj.means2d = io->means2d, b.proj.radii = io->radii, b.proj.n_isect = io->n_isect, b.proj.tile_ranks = nullptr;
-  b.isect.n_isect = cap > 0 ? cap : 1, b.isect.max_tile_count = max_hint;
+  b.proj.means2d = io->means2d, b.proj.radii = io->radii, b.proj.n_isect = io->n_isect;
+  b.isect.n_isect = cap > 0 ? cap : 1, b.isect.max_tile_count = max_hint, b.isect.near_target = io->near_target;
   b.raster.background = io->background, b.raster.render_colors = io->renders, b.raster.render_alphas = io->alphas;
 }
 

@@ -60,6 +60,10 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
     const int n2 = 2 * S * a.tw * a.th;
     for (int z = g; z < n2; z += gridDim.x * D4GS_PROJ_BLOCK) a.out.tile_counts[z] = 0;
   }
+  if ((d.flags & D4GS_LAZY_SORT) && a.out.lazy_ws) {  // the lazy-sort counters start from zero as well
+    const int64_t nl = d4gs_lazy_ws_elems(S, a.tw * a.th);
+    for (int64_t z = g; z < nl; z += (int64_t)gridDim.x * D4GS_PROJ_BLOCK) a.out.lazy_ws[z] = 0;
+  }
   if (dyn_block) preblend_bases(a, Bs);
 
   const bool active = g < N;
@@ -311,16 +315,58 @@ __global__ void __launch_bounds__(POSE_GPB * POSE_SLOTS) k_poses_fwd(const Poses
 // same histogram to hand out the slots, see binning.hip.)
 // ---------------------------------------------------------------------------------------------------
 constexpr int COUNT_THREADS = 1024;
-template <int COUNT_PER_THREAD>
+
+// D4GS_LAZY_SORT: the depth range of every sub-sample's binned instances, the scale of d4gs_depth_bucket - from a SAMPLE (every
+// 16th instance): the bucket map clamps outside the range, so any range gives a monotone, consistent partition; an exact one
+// costs 36 - 116 us in same-address atomics and reads for nothing
+__global__ void __launch_bounds__(256) k_depth_range(const float *__restrict__ depths, const int *__restrict__ tiles_touched, int N,
+                                                     uint32_t *__restrict__ zr) {
+  const int s = blockIdx.y;
+  uint32_t lo = 0u, hi = 0u;  // lo holds ~bits: the maximum of ~bits is the minimum of bits
+  for (int g = (blockIdx.x * 256 + threadIdx.x) * 16; g < N; g += gridDim.x * 256 * 16) {
+    const size_t i = (size_t)s * N + g;
+    if (tiles_touched[i] > 0) {
+      const uint32_t b = __float_as_uint(depths[i]);
+      lo = max(lo, ~b), hi = max(hi, b);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lo = max(lo, (uint32_t)__shfl_xor((int)lo, o)), hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+  __shared__ uint32_t slo[4], shi[4];
+  if ((threadIdx.x & 63) == 0) slo[threadIdx.x >> 6] = lo, shi[threadIdx.x >> 6] = hi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo = max(max(slo[0], slo[1]), max(slo[2], slo[3])), hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+    if (hi) atomicMax(zr + 2 * s, lo), atomicMax(zr + 2 * s + 1, hi);
+  }
+}
+
+// D4GS_LAZY_SORT: per tile, the near part = the nearest depth buckets up to (at least) `target` keys
+__global__ void __launch_bounds__(256) k_lazy_pivot(LazyWs w, int n_tiles, int target) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_tiles) return;
+  int cum = 0, b = 0;
+  for (; b < w.nb; b++) {
+    cum += w.hist[(size_t)t * w.nb + b];
+    if (cum >= target) break;
+  }
+  w.near[t] = cum;
+  w.pivot[t] = b < w.nb ? b : w.nb - 1;
+}
+
+template <int COUNT_PER_THREAD, bool LAZY>
 __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__restrict__ tile_rects,
                                                               const int *__restrict__ tiles_touched, int N, int S, int tw,
-                                                              int th, int *__restrict__ tile_counts, int *__restrict__ chunk_sums) {
-  extern __shared__ int hist[];  // [tiles]
+                                                              int th, int *__restrict__ tile_counts, int *__restrict__ chunk_sums,
+                                                              const float *__restrict__ depths, LazyWs lazy) {
+  extern __shared__ int hist[];  // [tiles] (+ LAZY: [tiles][nb] per depth bucket)
   __shared__ int wsum[COUNT_THREADS / 64];
   const int tiles = tw * th, tid = threadIdx.x;
   const int s = blockIdx.x % S, chunk = blockIdx.x / S;  // neighbouring blocks work on different sub-samples' counters
-  for (int z = tid; z < tiles; z += COUNT_THREADS) hist[z] = 0;
+  for (int z = tid; z < (LAZY ? tiles * (1 + lazy.nb) : tiles); z += COUNT_THREADS) hist[z] = 0;
   __syncthreads();
+  int *hist2 = hist + tiles;
+  const uint32_t zlo = LAZY ? ~lazy.zr[2 * s] : 0u, zhi = LAZY ? lazy.zr[2 * s + 1] : 0u;
   int touched = 0;  // this lane's share of the chunk's intersection count (fused scan: see d4gs_fused_scan)
 #pragma unroll
   for (int q = 0; q < COUNT_PER_THREAD; q++) {
@@ -332,8 +378,12 @@ __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__rest
     if (tt == 0) continue;
     const int2 rc = *reinterpret_cast<const int2 *>(tile_rects + i * 2);
     const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+    const int bk = LAZY ? d4gs_depth_bucket(depths[i], zlo, zhi, lazy.nb) : 0;
     for (int ty = y0; ty < y1; ty++)
-      for (int tx = x0; tx < x1; tx++) atomicAdd(&hist[ty * tw + tx], 1);
+      for (int tx = x0; tx < x1; tx++) {
+        atomicAdd(&hist[ty * tw + tx], 1);
+        if (LAZY) atomicAdd(&hist2[(ty * tw + tx) * lazy.nb + bk], 1);
+      }
   }
   if (chunk_sums) {
 #pragma unroll
@@ -345,6 +395,11 @@ __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__rest
     const int c = hist[z];
     if (c > 0) atomicAdd(tile_counts + (size_t)s * tiles + z, c);
   }
+  if (LAZY)
+    for (int z = tid; z < tiles * lazy.nb; z += COUNT_THREADS) {
+      const int c = hist2[z];
+      if (c > 0) atomicAdd(lazy.hist + (size_t)s * tiles * lazy.nb + z, c);
+    }
   if (chunk_sums && tid == 0) {
     int t = 0;
 #pragma unroll
@@ -461,6 +516,22 @@ extern "C" size_t d4gs_scan_ws_elems(int64_t n_instances) {  // (block sums of t
   return (size_t)((n_instances + COUNT_THREADS - 1) / COUNT_THREADS) + 64;
 }
 
+// D4GS_LAZY_SORT in effect?  (needs the LDS-aggregated counting pass and the scratch buffer; D4GS_LAZY=0 forces it off)
+bool d4gs_lazy_on(const D4gsDims *d, const D4gsProjOut *out) {
+  if (!(d->flags & D4GS_LAZY_SORT) || !out->lazy_ws || d->N <= 0) return false;
+  const char *env = getenv("D4GS_LAZY");
+  if (env && env[0] == '0') return false;
+  const size_t tiles = (size_t)((d->width + D4GS_TILE - 1) / D4GS_TILE) * ((d->height + D4GS_TILE - 1) / D4GS_TILE);
+  return sizeof(int) * tiles * (1 + d4gs_lazy_buckets((int)tiles)) <= 150 * 1024 && sizeof(int) * tiles <= 64 * 1024 &&
+         getenv("D4GS_COUNT_IN_PROJECT") == nullptr;
+}
+int d4gs_lazy_pivot_launch(const D4gsDims *d, const D4gsProjOut *out, int64_t near_target, hipStream_t stream) {
+  const int tiles = ((d->width + D4GS_TILE - 1) / D4GS_TILE) * ((d->height + D4GS_TILE - 1) / D4GS_TILE), nt = d->S * tiles;
+  const int target = near_target > 0 ? (int)(near_target > (1 << 20) ? (1 << 20) : near_target) : 1024;
+  D4GS_LAUNCH("k_lazy_pivot", k_lazy_pivot, dim3((nt + 255) / 256), dim3(256), 0, stream, d4gs_lazy_carve(out->lazy_ws, d->S, tiles), nt, target);
+  return d4gs_check_launch("k_lazy_pivot");
+}
+
 int d4gs_chunk_per_thread(const D4gsDims *d) {
   const int64_t blocks4 = (((int64_t)d->N + 4 * COUNT_THREADS - 1) / (4 * COUNT_THREADS)) * d->S;
   return blocks4 < 256 ? 1 : 4;
@@ -532,14 +603,29 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   if (a.count_apart) {
     const int pt = d4gs_chunk_per_thread(dims), per_block = COUNT_THREADS * pt;
     const int cblocks = ((dims->N + per_block - 1) / per_block) * dims->S;
-    if (pt == 1)
-      D4GS_LAUNCH("k_count_tiles", k_count_tiles<1>, dim3(cblocks), dim3(COUNT_THREADS), hist_bytes, stream,
-                  (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th,
-                  out->tile_counts, fused_chunks ? out->scan_ws : (int *)nullptr);
-    else
-      D4GS_LAUNCH("k_count_tiles", k_count_tiles<4>, dim3(cblocks), dim3(COUNT_THREADS), hist_bytes, stream,
-                  (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th,
-                  out->tile_counts, fused_chunks ? out->scan_ws : (int *)nullptr);
+    const bool lazy = d4gs_lazy_on(dims, out);
+    LazyWs lw{};
+    size_t cbytes = hist_bytes;
+    if (lazy) {  // depth range of every sub-sample first: it scales the (tile, depth bucket) histogram
+      lw = d4gs_lazy_carve(out->lazy_ws, dims->S, a.tw * a.th);
+      cbytes += hist_bytes * lw.nb;
+      const int rblocks = 8;
+      D4GS_LAUNCH("k_depth_range", k_depth_range, dim3(rblocks, dims->S), dim3(256), 0, stream, (const float *)out->depths,
+                  (const int *)out->tiles_touched, dims->N, lw.zr);
+    }
+#define D4GS_COUNT(PT_, LZ_)                                                                                                  \
+  do {                                                                                                                        \
+    if (cbytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_count_tiles<PT_, LZ_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); /* (+ the kernel's static LDS <= 160 KB) */ \
+    D4GS_LAUNCH("k_count_tiles", (k_count_tiles<PT_, LZ_>), dim3(cblocks), dim3(COUNT_THREADS), cbytes, stream,              \
+                (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th, out->tile_counts, \
+                fused_chunks ? out->scan_ws : (int *)nullptr, (const float *)out->depths, lw);                                \
+  } while (0)
+    if (pt == 1 && lazy) D4GS_COUNT(1, true);
+    else if (pt == 1) D4GS_COUNT(1, false);
+    else if (lazy) D4GS_COUNT(4, true);
+    else D4GS_COUNT(4, false);
+#undef D4GS_COUNT
+    // (the near / far pivot of every tile is chosen in d4gs_bin_sort, where the caller's D4gsIsect.near_target is known)
     rc = d4gs_check_launch("k_count_tiles");
     if (rc) return rc;
   }

@@ -690,18 +690,19 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
 // the shape (engine.row_mode_for; D4gsProjOut.n_isect[2..3]).  This fallback only knows the rows per (sub-sample, Gaussian)
 // instance the lists were sized for - large footprints go with dead rows: measured 1.8 rows per instance -> dense is 3 %
 // faster; 7.4 -> sparse is 13 % faster.
-static bool choose_sparse(int row_mode, int64_t n_isect, int64_t n_inst) {
+static bool choose_sparse(int row_mode, int64_t n_isect, int64_t n_inst, bool lazy) {
+  if (lazy) return true;  // D4GS_LAZY_SORT leaves the far part of an unflagged list as emitted: its dead rows have no sorted_emit
   if (row_mode == D4GS_ROWS_DENSE) return false;
   if (row_mode == D4GS_ROWS_SPARSE) return true;
   return n_isect >= 6 * (n_inst > 0 ? n_inst : 1);
 }
 
 template <int D, bool DEPTH>
-int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, hipStream_t stream) {
+int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, bool lazy, hipStream_t stream) {
   const int n_tiles = a.S * a.tw * a.th;
   const int blocks = ((n_tiles + 7) / 8) * 8;
   bool launched = false;
-  a.sparse = ga.sparse = choose_sparse(row_mode, n_isect, (int64_t)a.S * a.N) ? 1 : 0;
+  a.sparse = ga.sparse = choose_sparse(row_mode, n_isect, (int64_t)a.S * a.N, lazy) ? 1 : 0;
 #ifdef D4GS_VARIANTS  // the A/B build only (tests/libd4gs_variants.so): environment-selected reference variants, dense rows
   static const bool wave_per_tile = getenv("D4GS_BWD_WAVE_PER_TILE") != nullptr;  // variant A
   static const bool use_mfma = getenv("D4GS_BWD_MFMA") != nullptr;                // variant C
@@ -782,9 +783,10 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   ga.sy = (float)dims->height / 2.0f * (float)g->stats_batch_size * (float)dims->S;
   ga.max_wh = (float)(dims->width > dims->height ? dims->width : dims->height);
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
+  const bool lazy = d4gs_lazy_on(dims, proj);
 #define D4GS_CASE(DD)                                                                             \
   case DD:                                                                                        \
-    return dep ? launch_bwd<DD, true>(a, ga, isect->n_isect, g->row_mode, stream) : launch_bwd<DD, false>(a, ga, isect->n_isect, g->row_mode, stream);
+    return dep ? launch_bwd<DD, true>(a, ga, isect->n_isect, g->row_mode, lazy, stream) : launch_bwd<DD, false>(a, ga, isect->n_isect, g->row_mode, lazy, stream);
   switch (dims->D) {
     D4GS_CASE(1)
     D4GS_CASE(2)

@@ -38,6 +38,12 @@ struct RasterFwdArgs {
                    // sized for (see binning.hip); [2], [3]: this kernel's live-row sample
   int64_t cap, max_hint;
   float *seg_state;  // SEG instantiations: [tiles][D4GS_SEG_MAX][1 + NCH][256] boundary states (common.h "depth segments")
+  // D4GS_LAZY_SORT: pass 1 composites the (sorted) near part of every list and flags the tiles that did not saturate within it
+  // (their outputs are not written); pass 2, after the far parts of the flagged lists have been sorted, composites those tiles
+  // over their whole lists.  pass 0: one pass over whole lists.
+  const int32_t *lazy_near;
+  int32_t *lazy_flag;
+  int lazy_pass;
 #ifdef D4GS_TRACE  // A/B builds only (scripts/trace_wgs.py --fwd): per-workgroup wall clock {start, end}, hardware id, list entries,
   unsigned long long *trace;  // and the time spent in the staging / list-building / compositing phases of its batches
 #endif
@@ -131,7 +137,15 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 #pragma unroll
   for (int c = 0; c < NCH; c++) acc[c] = 0.f;
 
-  const int start = a.tile_offsets[t], end = a.tile_offsets[t + 1];
+  const int start = a.tile_offsets[t];
+  int end = a.tile_offsets[t + 1];
+  const int end_full = end;
+  bool has_far = false;  // workgroup-uniform
+  if (a.lazy_pass == 1) {
+    const int nn = a.lazy_near[t];
+    has_far = nn < end - start;
+    end = min(end, start + nn);
+  } else if (a.lazy_pass == 2 && !a.lazy_flag[t]) return;
   const size_t inst_base = (size_t)s * a.N;
   // SEG: the pixel's state (T, accumulated channels) is stored at every depth-segment boundary of the list and at its end, in
   // tile-local pixel order, for the segmented backward (raster_bwd.hip).  Slot 0 = final state, slot k = after k * seglen entries.
@@ -242,6 +256,12 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       if (e < end - start && e % seglen == 0) seg_store(e / seglen);
     }
   }
+  if (has_far) {  // lazy pass 1: did every pixel of the tile saturate inside the near part?  If not, the tile is done again in pass 2
+    if (!__syncthreads_and(done)) {
+      if (tid == 0) a.lazy_flag[t] = 1;
+      return;
+    }
+  }
   if constexpr (SEG) seg_store(0);
 
   // live-row sample (include/d4gs.h, D4gsProjOut.n_isect[2..3]): every `stride`-th tile adds its list length and the entries
@@ -256,7 +276,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     __syncthreads();
     if (tid == 0) {
       const int h = max(max(slive_hi[0], slive_hi[1]), max(slive_hi[2], slive_hi[3]));
-      atomicAdd(reinterpret_cast<unsigned long long *>(a.n_dev + 2), (unsigned long long)(end - start));
+      atomicAdd(reinterpret_cast<unsigned long long *>(a.n_dev + 2), (unsigned long long)(end_full - start));
       atomicAdd(reinterpret_cast<unsigned long long *>(a.n_dev + 3), (unsigned long long)(h - start + 1));
     }
   }
@@ -361,25 +381,38 @@ int d4gs_raster_fwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   a.n_dev = proj->n_isect, a.cap = isect->n_isect, a.max_hint = isect->max_tile_count;
   a.out = r->render_colors, a.alphas = r->render_alphas, a.last_ids = r->last_ids, a.final_T = r->final_T;
   a.seg_state = d4gs_seg_on(dims, isect, r) ? r->seg_state : nullptr;
+  a.lazy_near = nullptr, a.lazy_flag = nullptr, a.lazy_pass = 0;
+  const bool lazy = d4gs_lazy_on(dims, proj) && isect->n_isect > 0;
+  if (lazy) {
+    const LazyWs lw = d4gs_lazy_carve(proj->lazy_ws, dims->S, a.tw * a.th);
+    a.lazy_near = lw.near, a.lazy_flag = lw.flag, a.lazy_pass = 1;
+  }
 #ifdef D4GS_TRACE
   a.trace = getenv("D4GS_TRACE_FWD_PTR") ? (unsigned long long *)strtoull(getenv("D4GS_TRACE_FWD_PTR"), nullptr, 0) : nullptr;
 #endif
   const bool dep = dims->depth_mode != D4GS_DEPTH_NONE;
+  auto launch = [&](const RasterFwdArgs &aa) -> int {
 #define D4GS_CASE(DD)                                                   \
   case DD:                                                              \
-    return dep ? launch_fwd<DD, true>(a, stream) : launch_fwd<DD, false>(a, stream);
-  switch (dims->D) {
-    D4GS_CASE(1)
-    D4GS_CASE(2)
-    D4GS_CASE(3)
-    D4GS_CASE(4)
-    D4GS_CASE(5)
-    D4GS_CASE(8)
-    D4GS_CASE(16)
-    default:
-      d4gs_set_error("unsupported colour channel count D=%d (instantiated: 1,2,3,4,5,8,16; render wider colour "
-                     "vectors in chunks over the same projection / tile lists)", dims->D);
-      return D4GS_EINVAL;
-  }
+    return dep ? launch_fwd<DD, true>(aa, stream) : launch_fwd<DD, false>(aa, stream);
+    switch (dims->D) {
+      D4GS_CASE(1)
+      D4GS_CASE(2)
+      D4GS_CASE(3)
+      D4GS_CASE(4)
+      D4GS_CASE(5)
+      D4GS_CASE(8)
+      D4GS_CASE(16)
+      default:
+        d4gs_set_error("unsupported colour channel count D=%d (instantiated: 1,2,3,4,5,8,16; render wider colour "
+                       "vectors in chunks over the same projection / tile lists)", dims->D);
+        return D4GS_EINVAL;
+    }
 #undef D4GS_CASE
+  };
+  int rc = launch(a);
+  if (rc || !lazy) return rc;
+  if ((rc = d4gs_lazy_far_sort(dims, proj, isect, stream))) return rc;
+  a.lazy_pass = 2;
+  return launch(a);
 }

@@ -55,6 +55,13 @@ class RenderCfg:
     control_stats: dict | None = None  # optional densification-statistics sink, updated by the backward's gather epilogue
     #                                  (SURVEY 8f-1): {"xys_grad_norm_acc" f32[N], "vis_count" i64[N], "max_radii" f32[N],
     #                                  "batch_size" int, "update_max_radii" bool}
+    lazy_sort: bool | None = None  # D4GS_LAZY_SORT (include/d4gs.h): near / far partition of the tile lists, far parts sorted only
+    #                                  for tiles that did not saturate within the near part.  Opt-in (True, or the environment's
+    #                                  D4GS_LAZY_SORT=1 / auto): same image and gradients bit for bit, but the tail of a list behind
+    #                                  its tile's last contributor is then left UNSORTED in `flatten_ids`.  None -> resolved once per
+    #                                  render by `resolve_lazy` ("auto": on when the previous render of the shape measured < 30 % live
+    #                                  rows and lists of >= 2048 keys on average)
+    near_target: int = 0  # keys the near part of a list is aimed at (0: the library's 1024)
 
     @property
     def DP(self) -> int:
@@ -70,7 +77,7 @@ class RenderCfg:
 
     def dims(self) -> L.Dims:
         return L.Dims(self.N, self.G, self.K, self.T, self.S, self.D, self.width, self.height, self.depth_mode,
-                      self.flags | (L.EXACT_CULL if self.exact_cull else 0), self.n_sigmoid, self.near_plane, self.far_plane, self.eps2d, self.radius_clip)
+                      self.flags | (L.EXACT_CULL if self.exact_cull else 0) | (L.LAZY_SORT if self.lazy_sort else 0), self.n_sigmoid, self.near_plane, self.far_plane, self.eps2d, self.radius_clip)
 
 
 @dataclass
@@ -183,6 +190,42 @@ def _live_put(key, live, sampled):
         _LIVE_FRAC.move_to_end(key)
         while len(_LIVE_FRAC) > _SIZE_GUESS_MAX:
             _LIVE_FRAC.popitem(last=False)
+
+
+LAZY_SORT = os.environ.get("D4GS_LAZY_SORT", "0")  # "0" off (default), "1" on, "auto" by the measured live fraction
+assert LAZY_SORT in ("0", "1", "auto"), f"D4GS_LAZY_SORT={LAZY_SORT!r}"
+
+
+def resolve_lazy(cfg, dev):
+    """Fix cfg.lazy_sort / cfg.near_target for one render (once: forward and backward must agree on D4gsDims.flags)."""
+    if cfg.lazy_sort is None:
+        cfg.lazy_sort = LAZY_SORT == "1"
+        if LAZY_SORT == "auto":
+            key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
+            with _SIZE_LOCK:
+                f = _LIVE_FRAC.get(key)
+            guess = _guess_get(key)
+            tw, th = cfg.tiles
+            avg = (guess[0] / 1.25 / max(cfg.S * tw * th, 1)) if guess else 0.0
+            cfg.lazy_sort = f is not None and f < 0.3 and avg >= 2048  # (measured: cfg2 with 4x splats - 4 % live, 3 860 keys per
+            #   list - 1.53 -> 1.29 ms; with 2x splats - 16 %, 1 900 - 1.11 -> 1.18: the near part is whole depth buckets, 8 per list)
+    if cfg.lazy_sort and cfg.near_target <= 0:
+        key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
+        with _SIZE_LOCK:
+            f = _LIVE_FRAC.get(key)
+        guess = _guess_get(key)
+        tw, th = cfg.tiles
+        if f is not None and guess:  # about 2.5 x the entries a tile consumed on the previous render of the shape
+            cfg.near_target = max(256, int(2.5 * f * guess[0] / 1.25 / max(cfg.S * tw * th, 1)))
+    return cfg
+
+
+def _lazy_ws(cfg, dev):
+    if not cfg.lazy_sort:
+        return None
+    z = L.Sizes()
+    L.check(L.lib().d4gs_query_sizes(C.byref(cfg.dims()), C.byref(z)), "d4gs_query_sizes")
+    return torch.empty(int(z.lazy_ws), dtype=torch.int32, device=dev)
 
 
 def row_mode_for(cfg, dev):
@@ -373,7 +416,7 @@ class ProjectFn(torch.autograd.Function):
             radii=torch.empty(S, N, **i32), opac_act=torch.empty(N, **f32), ctab=torch.empty(N, cfg.DP, **f32),
             geom=torch.empty(S * N, L.GEOM_STRIDE, **f32), tile_rects=torch.empty(S * N, 2, **i32),
             tiles_touched=torch.empty(S * N, **i32),
-            isect_offsets=torch.empty(S * N, **i32), tile_ranks=None,
+            isect_offsets=torch.empty(S * N, **i32), lazy_ws=_lazy_ws(cfg, dev),
             tile_counts=torch.empty(2 * S * tw * th, **i32),
             tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(4, dtype=torch.int64, device=dev),
             scan_ws=torch.empty(lib.d4gs_scan_ws_elems(S * N), **i32),
@@ -569,7 +612,7 @@ class RasterFn(torch.autograd.Function):
         def raster(cap, max_hint):
             hint_used[0] = max_hint
             isect = L.fill(L.Isect(), **st.isect)
-            isect.n_isect, isect.max_tile_count = max(cap, 1), max_hint
+            isect.n_isect, isect.max_tile_count, isect.near_target = max(cap, 1), max_hint, cfg.near_target
             L.check(lib.d4gs_raster_fwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), _stream()),
                     "d4gs_raster_fwd")
 
@@ -578,7 +621,7 @@ class RasterFn(torch.autograd.Function):
             st.isect = dict(keys=torch.empty(m, dtype=torch.int64, device=dev), gid_of_emit=torch.empty(m, **i32),
                             sorted_gid=torch.empty(m, **i32), sorted_emit=torch.empty(m, **i32))
             isect = L.fill(L.Isect(), **st.isect)
-            isect.n_isect, isect.max_tile_count = m, max_hint
+            isect.n_isect, isect.max_tile_count, isect.near_target = m, max_hint, cfg.near_target
             L.check(lib.d4gs_bin_sort(C.byref(dims), C.byref(pout), C.byref(isect), _stream()), "d4gs_bin_sort")
             raster(cap, max_hint)
 
@@ -659,6 +702,7 @@ class FrameFn(torch.autograd.Function):
         dims = cfg.dims()
         pin = L.fill(L.ProjIn(), **st.proj_in)
         fio = L.fill(L.FrameIO(), **io)
+        fio.near_target = cfg.near_target
         pol = (C.c_int32 * NCH)(*blend_policy) if blended else None
         if blended:
             fio.policy = pol
@@ -732,6 +776,7 @@ class FrameFn(torch.autograd.Function):
             fg.stats_max_radii = L.ptr(cs["max_radii"])
             fg.stats_batch_size, fg.stats_update_max_radii = int(cs["batch_size"]), int(bool(cs.get("update_max_radii", False)))
         fio = L.fill(L.FrameIO(), **io)
+        fio.near_target = cfg.near_target
         if blended:
             fio.policy = st.policy
         L.check(lib.d4gs_backward(C.byref(dims), C.byref(L.fill(L.ProjIn(), **pi)), C.byref(fio), C.byref(fg),
@@ -855,6 +900,7 @@ def render_instances(cfg: RenderCfg, means, quats, scales, opacities, colors, mo
         rc, ra, m2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors, motion_coefs, rots,
                                                   transls, times, RTs, viewmat, Kmat, background)
         return rc[..., 1:], ra, m2d, radii, st
+    resolve_lazy(cfg, means.device)
     st = State(cfg)
     if cfg.N == 0:  # an empty scene (e.g. everything culled): the image is the background, nothing to launch
         _need_gpu(means)

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .engine import FrameFn, RenderCfg, State, _stream, frame_supported, render_instances
+from .engine import FrameFn, RenderCfg, State, _stream, frame_supported, render_instances, resolve_lazy
 
 POLICY_MEAN, POLICY_MAX, POLICY_MIN = 0, 1, 2
 
@@ -85,6 +85,8 @@ def render_exposure(
     control_stats: dict | None = None,
     deferred_size_check: bool = False,
     fused: bool = False,
+    lazy_sort: bool | None = None,
+    near_target: int = 0,
 ):
     """-> dict(renders [S,H,W,D'], alphas [S,H,W,1], blended [H,W,D'] | None, acc [H,W] | None,
                means2d [S,N,2], radii [S,N], state).
@@ -100,10 +102,11 @@ def render_exposure(
                     D=colors.shape[-1], width=width, height=height,
                     depth_mode=L.DEPTH_ED if return_depth else L.DEPTH_NONE, flags=flags, n_sigmoid=n_sigmoid,
                     exact_cull=exact_cull, grad_arena=grad_arena, control_stats=control_stats,
-                    deferred_size_check=deferred_size_check)
+                    deferred_size_check=deferred_size_check, lazy_sort=lazy_sort, near_target=near_target)
     if fused and frame_supported(cfg):
         # ONE autograd node over d4gs_forward / d4gs_backward: same kernels and bits as the staged chain below, a fraction
         # of its host work.  `means2d` is then a plain tensor; its gradient goes to st.xys_sink / st.v_means2d.
+        resolve_lazy(cfg, means.device)
         st = State(cfg)
         st.want_grad = torch.is_grad_enabled()
         pol = (reference_policy(cfg.NCH) if policy is None else list(policy)) if blend else None

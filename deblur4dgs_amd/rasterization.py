@@ -40,6 +40,8 @@ def rasterization(
     rasterize_mode: str = "classic",
     channel_chunk: int = 32,
     exact_cull: bool = True,
+    lazy_sort: bool | None = None,
+    near_target: int = 0,
     **_ignored,
 ):
     if viewmats.shape[0] != 1 or Ks.shape[0] != 1:
@@ -56,7 +58,7 @@ def rasterization(
     # tile lists (engine.channel_chunks), like gsplat's `channel_chunk`
     cfg = RenderCfg(N=N, G=0, K=0, T=0, S=1, D=colors.shape[-1], width=width, height=height,
                     depth_mode=_MODES[render_mode], flags=0, near_plane=near_plane, far_plane=far_plane, eps2d=eps2d,
-                    radius_clip=radius_clip, exact_cull=exact_cull)
+                    radius_clip=radius_clip, exact_cull=exact_cull, lazy_sort=lazy_sort, near_target=near_target)
     rc, ra, means2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors, None, None, None,
                                                   None, None, viewmats[0], Ks[0], bg)
     tw, th = cfg.tiles

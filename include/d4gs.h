@@ -43,6 +43,12 @@ enum { /* D4gsDims.flags */
   D4GS_RAW_PARAMS = 1,  /* quats/scales/opacities/motion_coefs are raw leaves: apply normalize/exp/sigmoid/softmax
                            (params.py:39-43).  When clear, scales/opacities are used as given (gsplat seam). */
   D4GS_RAW_COLORS = 2,  /* the first `n_sigmoid` colour channels are raw: apply sigmoid (params.py:40) */
+  D4GS_LAZY_SORT = 8,   /* occluded / large-footprint scenes (most of every tile list lies behind the tile's last contributor):
+                           every list is partitioned at emit time into a NEAR part (the nearest depth buckets, about
+                           D4gsIsect.near_target keys) and the rest; near parts are sorted and composited first, the far part of a
+                           list is sorted - and the tile composited again over its whole list - only if the tile did not
+                           saturate within the near part.  Same lists where they matter, same image and gradients bit for bit;
+                           needs D4gsProjOut.lazy_ws. */
   D4GS_EXACT_CULL = 4   /* bin a splat only into tiles that hold a pixel with alpha >= 1/255 (tight ellipse
                            sigma <= ln(255*opacity), intersected with gsplat's 3-sigma tile rectangle).  Pixels in
                            the dropped tiles would fail gsplat's alpha test anyway, so images and gradients are
@@ -97,7 +103,9 @@ typedef struct D4gsProjOut {
   int32_t *tiles_touched;  /* [S*N] */
   int32_t *isect_offsets;  /* [S*N] exclusive scan of tiles_touched (emission index base of every instance); complete after
                               d4gs_bin_sort: for small tile grids the binning stage finishes the scan itself */
-  int32_t *tile_ranks;     /* unused since the slots are handed out inside d4gs_bin_sort (kept for layout; may be NULL) */
+  int32_t *lazy_ws;        /* [D4gsSizes.lazy_ws] scratch of D4GS_LAZY_SORT (per (tile, depth bucket) counts, near counts, pivots,
+                              slot cursors, tile flags, depth range); NULL without the flag.  (Until v302 this slot was the
+                              unused `tile_ranks`.) */
   int32_t *tile_counts;    /* [2*S*tiles]: [0,T) splats per tile, [T,2T) per-tile slot cursors - zeroed by
                               d4gs_project_fwd and consumed by d4gs_bin_sort, which therefore runs once per projection
                               (a launch refused by the capacity check does not touch them); T = S*tiles */
@@ -121,6 +129,8 @@ typedef struct D4gsIsect {
                             * d4gs_raster_bwd needs the exact count. */
   int64_t max_tile_count;  /* [host] upper bound of D4gsProjOut.n_isect[1], checked on the device like n_isect
                             * (<= 0: unknown, launch every sort class) */
+  int64_t near_target;     /* [host] D4GS_LAZY_SORT: keys per tile list to aim the near part at (<= 0: 1024).  About twice the
+                            * entries a tile is expected to consume before it saturates. */
   uint64_t *keys;          /* [n_isect] scratch: (depth bits << 32 | emission index) per tile slot */
   int32_t *gid_of_emit;    /* [n_isect] Gaussian id of each emission index */
   int32_t *sorted_gid;     /* [n_isect] per-tile depth-sorted Gaussian ids (flatten_ids) */
@@ -213,6 +223,7 @@ typedef struct {
   int64_t isect_grad_row;                                        /* floats per intersection in isect_grad (isect_live: 1 byte) */
   int64_t bwd_partials;                                          /* D4gsLeafGrads.partials */
   int64_t seg_state;                                             /* D4gsRaster.seg_state; 0 = this configuration does not use depth segments */
+  int64_t lazy_ws;                                               /* D4gsProjOut.lazy_ws (int32 elements; needed with D4GS_LAZY_SORT only) */
   int32_t tiles_x, tiles_y, channels;                            /* tile grid; D + depth channel */
 } D4gsSizes;
 int d4gs_query_sizes(const D4gsDims *dims, D4gsSizes *sizes);
@@ -393,6 +404,7 @@ typedef struct D4gsFrameIO {
   int64_t *n_isect;        /* [4] device: {intersections, longest tile list, sampled entries, sampled live entries} (D4gsProjOut.n_isect) */
   const float *background; /* [D] or NULL */
   const int32_t *policy;   /* [host] [D+depth] blend policy per channel (0 mean, 1 max, 2 min) or NULL = all mean */
+  int64_t near_target;     /* [host] D4GS_LAZY_SORT: D4gsIsect.near_target of the frame (<= 0: 1024) */
 } D4gsFrameIO;
 typedef struct D4gsFrameGrads {
   const float *v_blended, *v_acc;     /* [H,W,D+depth], [H,W] or NULL */

@@ -622,3 +622,56 @@ def test_depth_segmented_backward_equals_the_whole_list_replay(mode, D, opaque, 
         check(case, name, b[name].cpu(), t[name].grad, GTOL, GFLIPS)
     check(case, "viewmat", b["V"].cpu()[:3], t["V"].grad[:3], 4 * VTOL, 0.0)  # (a sum over 12 000 large splats with cancellation: the
     #                                                     unsegmented replay misses VTOL on this scene by the same 1.5e-4)
+
+
+@pytest.mark.parametrize("mode,D,kind", [("RGB+ED", 3, "opaque"), ("RGB+ED", 3, "translucent"), ("RGB", 8, "mixed"), ("RGB+ED", 16, "opaque")])
+def test_lazy_far_sort_changes_nothing_but_the_dead_tails(mode, D, kind):
+    """D4GS_LAZY_SORT (include/d4gs.h): every tile list is partitioned at emit time into the nearest depth buckets (~ near_target keys) and
+    the rest; near parts are sorted and composited first, the far part only for tiles that did not saturate inside the near part.
+    Image, alpha, last contributors and every gradient must be BITWISE what the full sort gives - opaque scene: most tiles stop in
+    the near part; translucent: every tile needs its far part; mixed - and the lists must agree up to each tile's last contributor
+    (behind it the far part of a lazy list is not even written unless its tile needed it: that is the saving; the backward of a
+    lazy render takes sparse gradient rows, which never look there)."""
+    W, H, N = 96, 64, 14000
+    inp = static_inputs(N, W, H, seed=71 + D, dtype=torch.float32, D=D, scale_mul=14.0)
+    if kind == "opaque":
+        inp["opac"] = torch.full_like(inp["opac"], 0.98)
+    elif kind == "translucent":
+        inp["opac"] = inp["opac"] * 0.05
+    bg = torch.linspace(0.1, 0.9, D)
+    from deblur4dgs_amd.rasterization import rasterization
+
+    dev = torch.device("cuda:0")
+    out = {}
+    for lazy in (False, True):
+        t = {k: v.to(dev).clone().requires_grad_(k in ("means", "quats", "scales", "opac", "colors", "V")) for k, v in inp.items()}
+        rc, ra, info = rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"][None], t["K"][None], W, H,
+                                     backgrounds=bg.to(dev)[None], render_mode=mode, lazy_sort=lazy, near_target=300)
+        info["means2d"].retain_grad()
+        (rc.square().sum() + 0.7 * ra.sum()).backward()
+        torch.cuda.synchronize()
+        out[lazy] = dict(rc=rc.detach(), ra=ra.detach(), last=info["last_ids"].clone(), ids=info["flatten_ids"].clone(),
+                         offs=info["isect_offsets"].view(-1).long().cpu(), n=info["n_isect"], m2d=info["means2d"].grad.clone(),
+                         **{k: t[k].grad.clone() for k in ("means", "quats", "scales", "opac", "colors", "V")})
+    a, b = out[False], out[True]
+    assert a["n"] == b["n"] and torch.equal(a["offs"], b["offs"])
+    for k in ("rc", "ra", "last", "m2d", "means", "quats", "scales", "opac", "colors", "V"):
+        assert torch.equal(a[k], b[k]), k
+    offs = torch.cat([a["offs"], torch.tensor([a["n"]])])
+    n_list = offs[1:] - offs[:-1]
+    assert n_list.max() > 1000
+    tile_last = torch.nn.functional.max_pool2d(a["last"].float().view(1, 1, H, W), 16, ceil_mode=True).view(-1).long().cpu()
+    ia, ib = a["ids"].cpu(), b["ids"].cpu()
+    same_tail = 0
+    for tl in range(len(n_list)):
+        lo, hi = int(offs[tl]), int(offs[tl + 1])
+        if hi == lo:
+            continue
+        live = max(int(tile_last[tl]) - lo + 1, 0)
+        assert torch.equal(ia[lo:lo + live], ib[lo:lo + live]), tl       # what is composited / replayed: the same order
+        same_tail += int(torch.equal(ia[lo:hi], ib[lo:hi]))
+    tiles = int((n_list > 0).sum())
+    if kind == "opaque":
+        assert same_tail < 0.5 * tiles, (same_tail, tiles)   # most far parts were never sorted
+    if kind == "translucent":
+        assert same_tail == tiles, (same_tail, tiles)        # every tile needed (and got) its far part
