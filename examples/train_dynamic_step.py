@@ -21,7 +21,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from deblur4dgs_amd import engine  # noqa: E402
-from deblur4dgs_amd.control import ControlCfg, accumulate_from_model, cull_step, densify_step  # noqa: E402
+from deblur4dgs_amd.control import ControlCfg, accumulate_from_model, cull_step, densify_step, spatial_order_step  # noqa: E402
 from deblur4dgs_amd.losses import photometric_loss  # noqa: E402
 from deblur4dgs_amd.scene_model import GaussianParams, MotionBases, SceneModel  # noqa: E402
 from deblur4dgs_amd.synth import make_scene  # noqa: E402
@@ -130,6 +130,8 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, f
         if control_every and it > 0 and it % control_every == 0:  # adaptive control: N changes between steps
             n_split, n_dup = densify_step(model, stats, optimizers, cfg, global_step=it)
             n_cull = cull_step(model, stats, optimizers, cfg, global_step=it)
+            spatial_order_step(model, stats, optimizers)  # the control step rewrites every row anyway: leave them in Morton order of
+            #                                                the first camera's image plane (binning / gather locality)
             for v in stats.values():
                 v.zero_()
             params = [p for o in opts() for g in o.param_groups for p in g["params"]]
