@@ -149,7 +149,8 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   const size_t inst_base = (size_t)s * a.N;
   // SEG: the pixel's state (T, accumulated channels) is stored at every depth-segment boundary of the list and at its end, in
   // tile-local pixel order, for the segmented backward (raster_bwd.hip).  Slot 0 = final state, slot k = after k * seglen entries.
-  const int seglen = SEG ? d4gs_seg_len(end - start) : 0;
+  const int seglen = SEG ? d4gs_seg_len(end_full - start) : 0;  // (of the WHOLE list, as the backward computes it - a lazy first pass
+  //                                                                  composites a truncated one)
   float *seg_px = SEG ? a.seg_state + (size_t)t * D4GS_SEG_MAX * (1 + NCH) * 256 + ((y - ty * D4GS_TILE) * D4GS_TILE + (x - tx * D4GS_TILE)) : nullptr;
   auto seg_store = [&](int k) {
     if (inside) {

@@ -624,7 +624,8 @@ def test_depth_segmented_backward_equals_the_whole_list_replay(mode, D, opaque, 
     #                                                     unsegmented replay misses VTOL on this scene by the same 1.5e-4)
 
 
-@pytest.mark.parametrize("mode,D,kind", [("RGB+ED", 3, "opaque"), ("RGB+ED", 3, "translucent"), ("RGB", 8, "mixed"), ("RGB+ED", 16, "opaque")])
+@pytest.mark.parametrize("mode,D,kind", [("RGB+ED", 3, "opaque"), ("RGB+ED", 3, "translucent"), ("RGB", 8, "mixed"), ("RGB+ED", 16, "opaque"),
+                                         ("RGB+ED", 3, "opaque_long"), ("RGB+ED", 3, "mixed_long")])
 def test_lazy_far_sort_changes_nothing_but_the_dead_tails(mode, D, kind):
     """D4GS_LAZY_SORT (include/d4gs.h): every tile list is partitioned at emit time into the nearest depth buckets (~ near_target keys) and
     the rest; near parts are sorted and composited first, the far part only for tiles that did not saturate inside the near part.
@@ -632,9 +633,10 @@ def test_lazy_far_sort_changes_nothing_but_the_dead_tails(mode, D, kind):
     the near part; translucent: every tile needs its far part; mixed - and the lists must agree up to each tile's last contributor
     (behind it the far part of a lazy list is not even written unless its tile needed it: that is the saving; the backward of a
     lazy render takes sparse gradient rows, which never look there)."""
-    W, H, N = 96, 64, 14000
+    W, H, N = 96, 64, (40000 if kind.endswith("_long") else 14000)  # _long: lists beyond 2 048 keys - the depth segments of the few-tile
+    #                                                                   backward are then 512 entries long (the near part alone: 256)
     inp = static_inputs(N, W, H, seed=71 + D, dtype=torch.float32, D=D, scale_mul=14.0)
-    if kind == "opaque":
+    if kind.startswith("opaque"):
         inp["opac"] = torch.full_like(inp["opac"], 0.98)
     elif kind == "translucent":
         inp["opac"] = inp["opac"] * 0.05
@@ -659,7 +661,7 @@ def test_lazy_far_sort_changes_nothing_but_the_dead_tails(mode, D, kind):
         assert torch.equal(a[k], b[k]), k
     offs = torch.cat([a["offs"], torch.tensor([a["n"]])])
     n_list = offs[1:] - offs[:-1]
-    assert n_list.max() > 1000
+    assert n_list.max() > (2500 if kind.endswith("_long") else 1000)
     tile_last = torch.nn.functional.max_pool2d(a["last"].float().view(1, 1, H, W), 16, ceil_mode=True).view(-1).long().cpu()
     ia, ib = a["ids"].cpu(), b["ids"].cpu()
     same_tail = 0
@@ -671,7 +673,7 @@ def test_lazy_far_sort_changes_nothing_but_the_dead_tails(mode, D, kind):
         assert torch.equal(ia[lo:lo + live], ib[lo:lo + live]), tl       # what is composited / replayed: the same order
         same_tail += int(torch.equal(ia[lo:hi], ib[lo:hi]))
     tiles = int((n_list > 0).sum())
-    if kind == "opaque":
+    if kind.startswith("opaque"):
         assert same_tail < 0.5 * tiles, (same_tail, tiles)   # most far parts were never sorted
     if kind == "translucent":
         assert same_tail == tiles, (same_tail, tiles)        # every tile needed (and got) its far part
