@@ -48,27 +48,45 @@ __device__ __forceinline__ bool over_capacity(const int64_t *n_dev, int64_t cap,
 // has to be carried from the counting pass, splats of any footprint take the same path, and the 8-byte key stores
 // of a block fall into short contiguous runs.  Tile grids too big for the LDS histogram use global cursors.
 constexpr int EMIT_THREADS = 1024;
-// LAZY (D4GS_LAZY_SORT): every tile has TWO bins - the keys of the depth buckets up to the tile's pivot go to the front of its list
-// (the near part, lazy.near[t] keys), the others behind them; k_tile_sort orders the two parts separately, the far one on demand.
-template <int EMIT_PER_THREAD, bool LAZY>  // EMIT_PER_THREAD = d4gs_chunk_per_thread(dims), like k_count_tiles
+// LZ (D4GS_LAZY_SORT): 1 - only the keys of the depth buckets up to each tile's pivot are emitted, to the front of the tile's list (the
+// near part, lazy.near[t] keys); 2 - launched by d4gs_lazy_far_sort between the two composite passes: the other keys, behind the near
+// part, but only of the tiles the first pass flagged (the far part of a list whose tile saturated inside its near part is never
+// written, let alone sorted).  A pair's emission index does not depend on which launch writes it.
+template <int EMIT_PER_THREAD, int LZ>  // EMIT_PER_THREAD = d4gs_chunk_per_thread(dims), like k_count_tiles
 __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
-  extern __shared__ int bins[];  // [tiles] (LAZY: [tiles][2])
+  extern __shared__ int bins[];  // [tiles] (+ LZ: [tiles] pivots)
   if (over_capacity(a.n_dev, a.cap, a.max_hint)) return;
+  constexpr bool LAZY = LZ != 0;
   const int tiles = a.tw * a.th, tid = threadIdx.x;
   const int s = blockIdx.x % a.d.S, chunk = blockIdx.x / a.d.S;
   const int tbase = s * tiles, n_tiles_all = a.d.S * tiles;
   const bool lds = a.use_lds;
-  constexpr int NP = LAZY ? 2 : 1;
+  __shared__ int fbox[4];  // LZ == 2: bounding box of the sub-sample's flagged tiles
   if (lds) {
-    for (int z = tid; z < NP * tiles; z += EMIT_THREADS) bins[z] = 0;
+    for (int z = tid; z < tiles; z += EMIT_THREADS) bins[z] = 0;
+    if (LZ == 2 && tid == 0) fbox[0] = fbox[1] = 1 << 30, fbox[2] = fbox[3] = -1;
     __syncthreads();
   }
   const uint32_t zlo = LAZY ? ~a.lazy.zr[2 * s] : 0u, zhi = LAZY ? a.lazy.zr[2 * s + 1] : 0u;
-  int *piv = bins + NP * tiles;  // LAZY: the sub-sample's pivots, staged once per block (one read per key otherwise)
+  // LZ: the sub-sample's pivots, staged once per block (one read per key otherwise); 2: "never" for the tiles that were not flagged
+  int *piv = bins + tiles;
   if (LAZY) {
-    for (int z = tid; z < tiles; z += EMIT_THREADS) piv[z] = a.lazy.pivot[tbase + z];
+    for (int z = tid; z < tiles; z += EMIT_THREADS) {
+      int p = a.lazy.pivot[tbase + z];
+      if (LZ == 2) {
+        if (a.lazy.flag[tbase + z]) {
+          const int ty = z / a.tw, tx = z - ty * a.tw;
+          atomicMin(&fbox[0], tx), atomicMin(&fbox[1], ty), atomicMax(&fbox[2], tx), atomicMax(&fbox[3], ty);
+        } else {
+          p = 1 << 30;
+        }
+      }
+      piv[z] = p;
+    }
     __syncthreads();
+    if (LZ == 2 && fbox[2] < 0) return;  // (block-uniform) no tile of this sub-sample needs its far part
   }
+  auto taken = [&](int bk, int t) -> bool { return LZ == 1 ? bk <= piv[t] : bk > piv[t]; };
   int cnt[EMIT_PER_THREAD], rx[EMIT_PER_THREAD], ry[EMIT_PER_THREAD], bkq[EMIT_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < EMIT_PER_THREAD; q++) {
@@ -80,14 +98,17 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
       if (cnt[q] > 0) {
         const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
         rx[q] = rc.x, ry[q] = rc.y;
+        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+        if (LZ == 2 && (x0 > fbox[2] || x1 <= fbox[0] || y0 > fbox[3] || y1 <= fbox[1])) {
+          cnt[q] = 0;  // touches no flagged tile
+          continue;
+        }
         bkq[q] = LAZY ? d4gs_depth_bucket(a.depths[i], zlo, zhi, a.lazy.nb) : 0;
         if (lds) {
-          const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
           for (int ty = y0; ty < y1; ty++)
             for (int tx = x0; tx < x1; tx++) {
               const int t = ty * a.tw + tx;
-              if (LAZY) atomicAdd(&bins[2 * t + (bkq[q] > piv[t] ? 1 : 0)], 1);
-              else atomicAdd(&bins[t], 1);
+              if (!LAZY || taken(bkq[q], t)) atomicAdd(&bins[t], 1);
             }
         }
       }
@@ -95,19 +116,20 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
   }
   if (lds) {
     __syncthreads();
-    for (int z = tid; z < NP * tiles; z += EMIT_THREADS) {
+    for (int z = tid; z < tiles; z += EMIT_THREADS) {
       const int c = bins[z];
-      if (LAZY) {
-        const int t = tbase + (z >> 1), far = z & 1;
-        if (c > 0) bins[z] = a.tile_offsets[t] + (far ? a.lazy.near[t] : 0) + atomicAdd(a.lazy.cur + 2 * t + far, c);
-      } else if (c > 0) bins[z] = a.tile_offsets[tbase + z] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + z, c);
+      if (c == 0) continue;
+      const int t = tbase + z;
+      if (LZ == 1) bins[z] = a.tile_offsets[t] + atomicAdd(a.lazy.cur + 2 * t, c);
+      else if (LZ == 2) bins[z] = a.tile_offsets[t] + a.lazy.near[t] + atomicAdd(a.lazy.cur + 2 * t + 1, c);
+      else bins[z] = a.tile_offsets[t] + atomicAdd(a.tile_cursor + n_tiles_all + t, c);
     }
     __syncthreads();
   }
   // fused scan: emission index base of each of the block's 4096 instances = chunk base + exclusive scan of the counts in
   // instance order (q-major, then lane) - exactly what k_scan_apply would have written
   uint32_t ebase[EMIT_PER_THREAD];
-  if (a.nchunks) {
+  if (LZ != 2 && a.nchunks) {
     __shared__ int wsum[EMIT_THREADS / 64];
     int carry = a.chunk_base[s * a.nchunks + chunk];
     const int lane = tid & 63, wave = tid >> 6;
@@ -142,16 +164,15 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
     const int64_t i = (int64_t)s * a.d.N + g;
     const int x0 = rx[q] & 0xffff, x1 = rx[q] >> 16, y0 = ry[q] & 0xffff, y1 = ry[q] >> 16;
     const uint64_t hi = (uint64_t)__float_as_uint(a.depths[i]) << 32;
-    uint32_t e = a.nchunks ? ebase[q] : (uint32_t)a.isect_offsets[i];
+    uint32_t e = (LZ != 2 && a.nchunks) ? ebase[q] : (uint32_t)a.isect_offsets[i];
     for (int ty = y0; ty < y1; ty++)
-      for (int tx = x0; tx < x1; tx++) {
+      for (int tx = x0; tx < x1; tx++, e++) {
         const int t = ty * a.tw + tx;
-        const int slot = LAZY ? atomicAdd(&bins[2 * t + (bkq[q] > piv[t] ? 1 : 0)], 1)
-                         : lds ? atomicAdd(&bins[t], 1)
-                               : a.tile_offsets[tbase + t] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + t, 1);
+        if (LAZY && !taken(bkq[q], t)) continue;
+        const int slot = (LAZY || lds) ? atomicAdd(&bins[t], 1)
+                                       : a.tile_offsets[tbase + t] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + t, 1);
         a.keys[slot] = hi | e;
         a.gid_of_emit[e] = g;
-        e++;
       }
   }
 }
@@ -460,13 +481,9 @@ int launch_sorts(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect 
 
 }  // namespace
 
-int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream) {
-  if (isect->n_isect <= 0) return D4GS_OK;
-  if (isect->n_isect >= (int64_t)0x7fffffff) {
-    d4gs_set_error("n_isect=%lld exceeds int32 indexing", (long long)isect->n_isect);
-    return D4GS_ECAPACITY;
-  }
-  EmitArgs e;
+namespace {
+
+int fill_emit_args(EmitArgs &e, const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect) {
   e.d = *dims;
   e.depths = proj->depths;
   e.tile_rects = proj->tile_rects;
@@ -480,43 +497,69 @@ int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gs
   e.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
   e.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
   e.n_dev = proj->n_isect, e.cap = isect->n_isect, e.max_hint = isect->max_tile_count;
-  const int pt = d4gs_chunk_per_thread(dims), per_block = EMIT_THREADS * pt;
+  const int per_block = EMIT_THREADS * d4gs_chunk_per_thread(dims);
   if (e.nchunks && e.nchunks != (dims->N + per_block - 1) / per_block) {  // k_count_tiles' chunks must be this kernel's
     d4gs_set_error("internal: fused scan chunking mismatch (%d vs %d)", e.nchunks, (dims->N + per_block - 1) / per_block);
     return D4GS_EINVAL;
   }
-  const size_t bins_bytes = sizeof(int) * (size_t)e.tw * e.th;
-  e.use_lds = bins_bytes <= 64 * 1024;
-  const bool lazy = d4gs_lazy_on(dims, proj);
+  e.use_lds = sizeof(int) * (size_t)e.tw * e.th <= 64 * 1024;
   e.lazy = LazyWs{};
-  if (lazy) {  // every tile's near / far pivot first (the caller's near_target is known here, not in d4gs_project_fwd)
-    e.lazy = d4gs_lazy_carve(proj->lazy_ws, dims->S, e.tw * e.th);
-    int rc = d4gs_lazy_pivot_launch(dims, proj, isect->near_target, stream);
-    if (rc) return rc;
-  }
+  return D4GS_OK;
+}
+
+// lz: 0 plain, 1 / 2 the near parts / the flagged tiles' far parts of a D4GS_LAZY_SORT frame (k_emit)
+int launch_emit(const EmitArgs &e, const D4gsDims *dims, int lz, hipStream_t stream) {
+  const int pt = d4gs_chunk_per_thread(dims), per_block = EMIT_THREADS * pt;
   const unsigned eblocks = (unsigned)(((dims->N + per_block - 1) / per_block) * dims->S);
-  const size_t ebytes = e.use_lds ? bins_bytes * (lazy ? 3 : 1) : 0;
+  const size_t ebytes = e.use_lds ? sizeof(int) * (size_t)e.tw * e.th * (lz ? 2 : 1) : 0;
 #define D4GS_EMIT(PT_, LZ_)                                                                                               \
   do {                                                                                                                    \
     if (ebytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_emit<PT_, LZ_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); \
     D4GS_LAUNCH("k_emit", (k_emit<PT_, LZ_>), dim3(eblocks), dim3(EMIT_THREADS), ebytes, stream, e);                     \
   } while (0)
-  if (pt == 1 && lazy) D4GS_EMIT(1, true);
-  else if (pt == 1) D4GS_EMIT(1, false);
-  else if (lazy) D4GS_EMIT(4, true);
-  else D4GS_EMIT(4, false);
+  if (pt == 1) {
+    if (lz == 0) D4GS_EMIT(1, 0);
+    else if (lz == 1) D4GS_EMIT(1, 1);
+    else D4GS_EMIT(1, 2);
+  } else {
+    if (lz == 0) D4GS_EMIT(4, 0);
+    else if (lz == 1) D4GS_EMIT(4, 1);
+    else D4GS_EMIT(4, 2);
+  }
 #undef D4GS_EMIT
-  int rc = d4gs_check_launch("k_emit");
+  return d4gs_check_launch("k_emit");
+}
+
+}  // namespace
+
+int d4gs_bin_sort_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream) {
+  if (isect->n_isect <= 0) return D4GS_OK;
+  if (isect->n_isect >= (int64_t)0x7fffffff) {
+    d4gs_set_error("n_isect=%lld exceeds int32 indexing", (long long)isect->n_isect);
+    return D4GS_ECAPACITY;
+  }
+  EmitArgs e;
+  int rc = fill_emit_args(e, dims, proj, isect);
   if (rc) return rc;
+  const bool lazy = d4gs_lazy_on(dims, proj);
+  if (lazy) {  // every tile's near / far pivot first (the caller's near_target is known here, not in d4gs_project_fwd)
+    e.lazy = d4gs_lazy_carve(proj->lazy_ws, dims->S, e.tw * e.th);
+    if ((rc = d4gs_lazy_pivot_launch(dims, proj, isect->near_target, stream))) return rc;
+  }
+  if ((rc = launch_emit(e, dims, lazy ? 1 : 0, stream))) return rc;
   return launch_sorts(dims, proj, isect, lazy ? 1 : 0, stream);
 }
 
 // D4GS_LAZY_SORT, second half (called by d4gs_raster_fwd between its two composite passes): the far parts of the lists whose tile
-// the first pass flagged are sorted.  The far parts of the other lists - rows behind their tile's last contributor - are left as
-// emitted: nothing composites or replays them, and the backward of a lazy render always takes SPARSE gradient rows (raster_bwd.hip),
-// which never touches a dead row (copying their emission indices for the dense zero-fill cost 176 us on cfg2 with 4x splats -
-// more than the sort it saved).
+// the first pass flagged are emitted and sorted.  The far parts of the other lists - rows behind their tile's last contributor - are
+// never written: nothing composites or replays them, and the backward of a lazy render always takes SPARSE gradient rows
+// (raster_bwd.hip), which never touches a dead row (copying their emission indices for the dense zero-fill cost 176 us on cfg2 with
+// 4x splats - more than the sort it saved).
 int d4gs_lazy_far_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream) {
+  EmitArgs e;
+  int rc = fill_emit_args(e, dims, proj, isect);
+  if (rc) return rc;
+  e.lazy = d4gs_lazy_carve(proj->lazy_ws, dims->S, e.tw * e.th);
+  if ((rc = launch_emit(e, dims, 2, stream))) return rc;
   return launch_sorts(dims, proj, isect, 2, stream);
 }
-
