@@ -44,10 +44,10 @@ enum { /* D4gsDims.flags */
                            (params.py:39-43).  When clear, scales/opacities are used as given (gsplat seam). */
   D4GS_RAW_COLORS = 2,  /* the first `n_sigmoid` colour channels are raw: apply sigmoid (params.py:40) */
   D4GS_LAZY_SORT = 8,   /* occluded / large-footprint scenes (most of every tile list lies behind the tile's last contributor):
-                           every list is partitioned at emit time into a NEAR part (the nearest depth buckets, about
-                           D4gsIsect.near_target keys) and the rest; near parts are sorted and composited first, the far part of a
-                           list is sorted - and the tile composited again over its whole list - only if the tile did not
-                           saturate within the near part.  Same lists where they matter, same image and gradients bit for bit;
+                           every list is split into a NEAR part (the nearest depth buckets, about D4gsIsect.near_target keys)
+                           and the rest; near parts are emitted, sorted and composited first, the far part of a list is
+                           emitted and sorted - and the tile composited again over its whole list - only if the tile did not
+                           saturate within the near part (d4gs_raster_fwd does that between its two passes).  Same lists where they matter, same image and gradients bit for bit;
                            needs D4gsProjOut.lazy_ws. */
   D4GS_EXACT_CULL = 4   /* bin a splat only into tiles that hold a pixel with alpha >= 1/255 (tight ellipse
                            sigma <= ln(255*opacity), intersected with gsplat's 3-sigma tile rectangle).  Pixels in
