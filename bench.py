@@ -638,8 +638,12 @@ def main():
                     if not views_primary else f"views sharded x{world} (data parallel), RCCL gradient all-reduce")},
         "instances_per_s": value * S,
     }
+    lazy_on = bool(getattr(getattr(st, "cfg", None), "lazy_sort", False))
     if args.lazy_sort:
         out["config"]["workload"] += "; D4GS_LAZY_SORT"
+    # the library's default (D4GS_LAZY_SORT=auto) decides by the previous render's live-row fraction and list length; say what it did
+    out["config"]["lazy_sort"] = "forced on (--lazy-sort)" if args.lazy_sort else ("on (auto)" if lazy_on else "off (auto)") \
+        if os.environ.get("D4GS_LAZY_SORT", "auto") == "auto" else ("on" if lazy_on else "off")
     if args.spatial_order:
         out["config"]["workload"] += f"; Gaussians in Morton order ({args.spatial_order}; control.spatial_order_step)"
     if args.share > 1:

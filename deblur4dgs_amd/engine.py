@@ -56,11 +56,10 @@ class RenderCfg:
     #                                  (SURVEY 8f-1): {"xys_grad_norm_acc" f32[N], "vis_count" i64[N], "max_radii" f32[N],
     #                                  "batch_size" int, "update_max_radii" bool}
     lazy_sort: bool | None = None  # D4GS_LAZY_SORT (include/d4gs.h): near / far partition of the tile lists, far parts sorted only
-    #                                  for tiles that did not saturate within the near part.  Opt-in (True, or the environment's
-    #                                  D4GS_LAZY_SORT=1 / auto): same image and gradients bit for bit, but the tail of a list behind
+    #                                  for tiles that did not saturate within the near part.  Same image and gradients bit for bit, but the tail of a list behind
     #                                  its tile's last contributor is then left UNSORTED in `flatten_ids`.  None -> resolved once per
-    #                                  render by `resolve_lazy` ("auto": on when the previous render of the shape measured < 30 % live
-    #                                  rows and lists of >= 2048 keys on average)
+    #                                  render by `resolve_lazy` (D4GS_LAZY_SORT=auto, the default: on when the previous render of the
+    #                                  shape measured < 50 % live rows and lists of >= 1000 keys on average)
     near_target: int = 0  # keys the near part of a list is aimed at (0: the library's 1024)
 
     @property
@@ -192,8 +191,15 @@ def _live_put(key, live, sampled):
             _LIVE_FRAC.popitem(last=False)
 
 
-LAZY_SORT = os.environ.get("D4GS_LAZY_SORT", "0")  # "0" off (default), "1" on, "auto" by the measured live fraction
+# "auto" (default): by the measured live fraction, "1" always, "0" never.  `rasterization()` - the gsplat seam, whose `info` exposes
+# the sorted lists - only follows "1" or an explicit lazy_sort=True (behind a tile's last contributor a lazy list is unsorted)
+LAZY_SORT = os.environ.get("D4GS_LAZY_SORT", "auto")
 assert LAZY_SORT in ("0", "1", "auto"), f"D4GS_LAZY_SORT={LAZY_SORT!r}"
+# "auto" turns it on below this live-row fraction and from this many keys per tile list, both measured by the previous render of the
+# shape (A/B hook: D4GS_LAZY_AUTO="0.5,1000").  profiles/r04t_lazy_auto_stats.txt: cfg2 (95 % live, 940 keys) and cfg3 (88 %) and the
+# reference's training shape (100 %) stay off; cfg2 with 2x splats (16 %, 1 670) 1.113 -> 1.095 ms, with 4x (4 %, 3 870) 1.52 -> 1.11,
+# cfg5 (20 %, 1 150) 9.7 -> 9.08, the training shape with 4x splats (9 %, 1 840) 1.79 -> 1.73 - no workload measured loses
+LAZY_AUTO_LIVE, LAZY_AUTO_KEYS = (float(x) for x in os.environ.get("D4GS_LAZY_AUTO", "0.5,1000").split(","))
 
 
 def resolve_lazy(cfg, dev):
@@ -207,8 +213,7 @@ def resolve_lazy(cfg, dev):
             guess = _guess_get(key)
             tw, th = cfg.tiles
             avg = (guess[0] / 1.25 / max(cfg.S * tw * th, 1)) if guess else 0.0
-            cfg.lazy_sort = f is not None and f < 0.3 and avg >= 2048  # (measured: cfg2 with 4x splats - 4 % live, 3 860 keys per
-            #   list - 1.53 -> 1.29 ms; with 2x splats - 16 %, 1 900 - 1.11 -> 1.18: the near part is whole depth buckets, 8 per list)
+            cfg.lazy_sort = f is not None and f < LAZY_AUTO_LIVE and avg >= LAZY_AUTO_KEYS
     if cfg.lazy_sort and cfg.near_target <= 0:
         key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
         with _SIZE_LOCK:

@@ -11,6 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
+from . import engine
 from .engine import RenderCfg, render_instances
 
 _MODES = {"RGB": L.DEPTH_NONE, "RGB+ED": L.DEPTH_ED, "RGB+D": L.DEPTH_D}
@@ -56,6 +57,8 @@ def rasterization(
     bg = None if backgrounds is None else backgrounds[0]
     # any channel count: the engine composites it in chunks of <= 16 channels over one projection / one set of sorted
     # tile lists (engine.channel_chunks), like gsplat's `channel_chunk`
+    if lazy_sort is None:  # `info["flatten_ids"]` is part of this seam: lazy lists (unsorted behind a tile's last contributor) only on request
+        lazy_sort = engine.LAZY_SORT == "1"
     cfg = RenderCfg(N=N, G=0, K=0, T=0, S=1, D=colors.shape[-1], width=width, height=height,
                     depth_mode=_MODES[render_mode], flags=0, near_plane=near_plane, far_plane=far_plane, eps2d=eps2d,
                     radius_clip=radius_clip, exact_cull=exact_cull, lazy_sort=lazy_sort, near_target=near_target)
