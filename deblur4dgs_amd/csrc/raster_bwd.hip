@@ -444,23 +444,29 @@ struct GatherArgs {
 // The rows of the 64 instances a wave owns (same sub-sample, consecutive Gaussians) form ONE contiguous span of
 // isect_grad: the wave streams it into LDS with coalesced loads and every lane then sums its own rows from there, in
 // the same k order as a direct read (bit-identical).  Spans longer than the LDS budget (wide splats) take several chunks.
-constexpr int GATHER_THREADS = 128, GATHER_ROWS = 192;  // rows of LDS per wave
+// Round 4: a block owns 64 Gaussians and its 4 waves are 4 sub-sample SLOTS (wave w gathers sub-samples w, w + 4, ...), like
+// k_project_bwd: the kernel used to loop over the S sub-samples inside ONE wave per 64 Gaussians - N / 64 waves in all (4 688 on
+// cfg2 / cfg3, 2 188 on the reference's training shape), each a chain of S dependent flag / row fetches; 2 waves per SIMD resident
+// on average (profiles/r04t_pmc_gather.txt).  The per-Gaussian sums over the sub-samples (opacity, colours, densification statistics)
+// keep their order: after every round of 4 sub-samples the slots hand their contributions to wave 0 through LDS and wave 0 adds
+// them in ascending s - bit for bit what the single wave computed.
+constexpr int GATHER_ROWS = 192;                        // rows of LDS per wave
 constexpr int GATHER_SC = 1024;                         // rows per super-chunk of the cooperative sparse path (16 flags per lane)
-template <int D, bool DEPTH, bool SPARSE>
-__global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
+template <int D, bool DEPTH, bool SPARSE, int SLOTS /* waves per block: 4, or S when the call has fewer sub-samples */>
+__global__ void __launch_bounds__(SLOTS * 64) k_gather(const GatherArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int R = 6 + NCH;
-  __shared__ __attribute__((aligned(16))) float stage[(GATHER_THREADS / 64) * GATHER_ROWS * R];
-  __shared__ uint32_t slive[SPARSE ? (GATHER_THREADS / 64) * 64 : 1];  // flags of a chunk as 4-byte words (<= GATHER_ROWS + 3 bytes)
+  __shared__ __attribute__((aligned(16))) float stage[SLOTS * GATHER_ROWS * R];
+  __shared__ uint32_t slive[SPARSE ? SLOTS * 64 : 1];  // flags of a chunk as 4-byte words (<= GATHER_ROWS + 3 bytes)
   // cooperative sparse path (super-chunks of SC rows): the flags, the exclusive live-row count in front of every 16-row group
   // and the compacted list of live rows
-  __shared__ __attribute__((aligned(16))) uint32_t sflag[SPARSE ? (GATHER_THREADS / 64) * (GATHER_SC / 4) : 1];
-  __shared__ uint16_t sgrp[SPARSE ? (GATHER_THREADS / 64) * (GATHER_SC / 16 + 1) : 1];
-  __shared__ uint16_t slist[SPARSE ? (GATHER_THREADS / 64) * GATHER_SC : 1];
+  __shared__ __attribute__((aligned(16))) uint32_t sflag[SPARSE ? SLOTS * (GATHER_SC / 4) : 1];
+  __shared__ uint16_t sgrp[SPARSE ? SLOTS * (GATHER_SC / 16 + 1) : 1];
+  __shared__ uint16_t slist[SPARSE ? SLOTS * GATHER_SC : 1];
   static_assert(GATHER_ROWS + 6 <= 256, "one flag word per lane");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.x * 64 + lane;
   const bool in = g < a.N;
   float *mine = stage + wv * GATHER_ROWS * R;
   uint32_t *mylive32 = slive + (SPARSE ? wv * 64 : 0);
@@ -477,22 +483,26 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
   // the (count, offset) pair of the next sub-sample is fetched while the current one is streamed and summed
   const size_t gi = in ? g : a.N - 1;
   // (an overflowed render never wrote isect_offsets - k_emit returned early: do not read it, stream nothing)
-  int cnt_n = (in && !overflow) ? a.tiles_touched[gi] : 0, off_n = overflow ? 0 : a.isect_offsets[gi];
-  for (int s = 0; s < a.S; s++) {
+  int cnt_n = 0, off_n = 0;
+  if (wv < a.S) cnt_n = (in && !overflow) ? a.tiles_touched[(size_t)wv * a.N + gi] : 0, off_n = overflow ? 0 : a.isect_offsets[(size_t)wv * a.N + gi];
+  static_assert(GATHER_ROWS * R >= 64 * (3 + D), "the hand-off record of a slot lives in its stage slice");
+  for (int s0 = 0; s0 < a.S; s0 += SLOTS) {
+    const int s = s0 + wv;  // (wave-uniform)
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.f;
+    if (s < a.S) {
     const size_t i = (size_t)s * a.N + gi;
     const int cnt = cnt_n, off = off_n;
-    if (s + 1 < a.S) {
-      cnt_n = (in && !overflow) ? a.tiles_touched[i + a.N] : 0;
-      off_n = overflow ? 0 : a.isect_offsets[i + a.N];
+    if (s + SLOTS < a.S) {
+      cnt_n = (in && !overflow) ? a.tiles_touched[i + (size_t)SLOTS * a.N] : 0;
+      off_n = overflow ? 0 : a.isect_offsets[i + (size_t)SLOTS * a.N];
     }
     // span of the wave: [first lane's offset, last lane's offset + count)
     const int base = __builtin_amdgcn_readfirstlane(off);
     int endl = overflow ? 0 : off + cnt;  // overflowed lists: the offsets index past the buffer - nothing is streamed
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) endl = max(endl, __shfl_xor(endl, o));
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = 0.f;
     // the span is streamed in chunks of GATHER_ROWS rows; a lane's rows [off, off + cnt) are contiguous, so it adds
     // the part of them that lies in the current chunk - always in ascending k, whatever the chunking.  The copy moves
     // 16-byte words: the span start is rounded down to a row whose byte offset is a multiple of 16 (every APER-th row;
@@ -660,21 +670,34 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_gather(const GatherArgs a) {
       a.v_conics[i * 3 + 1] = acc[3];
       a.v_conics[i * 3 + 2] = acc[4];
       a.v_depths[i] = DEPTH ? acc[6 + (DEPTH ? D : 0)] : 0.f;
-      if (stats) {
-        const int r = a.radii[i];
-        if (r > 0) {
-          const float gx = acc[0] * a.sx, gy = acc[1] * a.sy;
-          st_acc += sqrtf(gx * gx + gy * gy);
-          st_vis += 1;
-          st_mr = fmaxf(st_mr, (float)r / a.max_wh);
+    }
+    }  // s < S
+    // hand-off: (v_opacity, v_colour[D], v_x, v_y) of this slot's sub-sample, element-major in the slot's (now idle) stage slice
+    mine[lane] = acc[5];
+#pragma unroll
+    for (int c = 0; c < D; c++) mine[(1 + c) * 64 + lane] = acc[6 + c];
+    mine[(1 + D) * 64 + lane] = acc[0], mine[(2 + D) * 64 + lane] = acc[1];
+    __syncthreads();
+    if (wv == 0) {
+      for (int w = 0; w < SLOTS && s0 + w < a.S; w++) {  // ascending s: the order of the single-wave loop
+        const float *rec = stage + w * GATHER_ROWS * R;
+        if (stats && in) {
+          const int r = a.radii[(size_t)(s0 + w) * a.N + g];
+          if (r > 0) {
+            const float gx = rec[(1 + D) * 64 + lane] * a.sx, gy = rec[(2 + D) * 64 + lane] * a.sy;
+            st_acc += sqrtf(gx * gx + gy * gy);
+            st_vis += 1;
+            st_mr = fmaxf(st_mr, (float)r / a.max_wh);
+          }
         }
+        vo += rec[lane];
+#pragma unroll
+        for (int c = 0; c < D; c++) vc[c] += rec[(1 + c) * 64 + lane];
       }
     }
-    vo += acc[5];
-#pragma unroll
-    for (int c = 0; c < D; c++) vc[c] += acc[6 + c];
+    __syncthreads();  // (the slices are stages again in the next round)
   }
-  if (!in) return;
+  if (!in || wv != 0) return;
   if (stats) {
     a.stats_acc[g] = st_acc;
     a.stats_vis[g] = st_vis;
@@ -742,10 +765,20 @@ int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, 
   }
   int rc = d4gs_check_launch("k_raster_bwd");
   if (rc) return rc;
-  if (ga.sparse)
-    D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH, true>), dim3((ga.N + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, stream, ga);
-  else
-    D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH, false>), dim3((ga.N + GATHER_THREADS - 1) / GATHER_THREADS), dim3(GATHER_THREADS), 0, stream, ga);
+  // 4 sub-sample slots per block; a call with fewer sub-samples (a rank's share of an exposure-sharded frame) would idle the rest
+  const int slots = ga.S >= 3 ? 4 : ga.S == 2 ? 2 : 1;
+  const dim3 ggrid((ga.N + 63) / 64), gblock(slots * 64);
+#define D4GS_GATHER(SP_, SL_) D4GS_LAUNCH("k_gather", (k_gather<D, DEPTH, SP_, SL_>), ggrid, gblock, 0, stream, ga)
+  if (ga.sparse) {
+    if (slots == 4) D4GS_GATHER(true, 4);
+    else if (slots == 2) D4GS_GATHER(true, 2);
+    else D4GS_GATHER(true, 1);
+  } else {
+    if (slots == 4) D4GS_GATHER(false, 4);
+    else if (slots == 2) D4GS_GATHER(false, 2);
+    else D4GS_GATHER(false, 1);
+  }
+#undef D4GS_GATHER
   return d4gs_check_launch("k_gather");
 }
 
