@@ -450,13 +450,20 @@ struct GatherArgs {
 // on average (profiles/r04t_pmc_gather.txt).  The per-Gaussian sums over the sub-samples (opacity, colours, densification statistics)
 // keep their order: after every round of 4 sub-samples the slots hand their contributions to wave 0 through LDS and wave 0 adds
 // them in ascending s - bit for bit what the single wave computed.
-constexpr int GATHER_ROWS = 192;                        // rows of LDS per wave
+// rows of LDS per wave: wide rows (D >= 8: 56 - 92 bytes) take half the rows, i.e. about the same bytes - the training shape's gather
+// 91 -> 77 us with twice the blocks per CU; narrow rows lose with smaller stages (cfg2 50 -> 53 -> 61 us at 128 / 96;
+// profiles/r04t_ab_gather_rows.txt)
+#ifndef D4GS_GATHER_ROWS_SPARSE
+#define D4GS_GATHER_ROWS_SPARSE 192
+#endif
+constexpr int gather_rows(int D, bool sparse) { return D >= 8 ? 96 : sparse ? D4GS_GATHER_ROWS_SPARSE : 192; }
 constexpr int GATHER_SC = 1024;                         // rows per super-chunk of the cooperative sparse path (16 flags per lane)
 template <int D, bool DEPTH, bool SPARSE, int SLOTS /* waves per block: 4, or S when the call has fewer sub-samples */>
 __global__ void __launch_bounds__(SLOTS * 64) k_gather(const GatherArgs a) {
   constexpr int NCH = D + (DEPTH ? 1 : 0);
   constexpr int DP = (D + 3) & ~3;
   constexpr int R = 6 + NCH;
+  constexpr int GATHER_ROWS = gather_rows(D, SPARSE);
   __shared__ __attribute__((aligned(16))) float stage[SLOTS * GATHER_ROWS * R];
   __shared__ uint32_t slive[SPARSE ? SLOTS * 64 : 1];  // flags of a chunk as 4-byte words (<= GATHER_ROWS + 3 bytes)
   // cooperative sparse path (super-chunks of SC rows): the flags, the exclusive live-row count in front of every 16-row group
