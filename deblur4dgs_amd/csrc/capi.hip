@@ -11,7 +11,7 @@ int d4gs_project_fwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOu
 int d4gs_bin_sort_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, hipStream_t);
 int d4gs_raster_fwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, const D4gsRaster *, hipStream_t);
 int d4gs_raster_bwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, const D4gsRaster *,
-                         const D4gsRasterGrads *, hipStream_t);
+                         const D4gsRasterGrads *, const BlendAdj *, hipStream_t);
 int d4gs_project_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, const float *, const float *,
                           const float *, const float *, const float *, const D4gsLeafGrads *, hipStream_t);
 int d4gs_poses_fwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsPoses *, hipStream_t);
@@ -253,7 +253,7 @@ int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
     d4gs_set_error("d4gs_raster_bwd: fused statistics need vis_count, max_radii, radii and a positive batch size");
     return D4GS_EINVAL;
   }
-  return d4gs_raster_bwd_impl(dims, proj, isect, r, g, (hipStream_t)stream);
+  return d4gs_raster_bwd_impl(dims, proj, isect, r, g, nullptr, (hipStream_t)stream);
 }
 
 int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *proj, const float *v_means2d,

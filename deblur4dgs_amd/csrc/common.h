@@ -358,6 +358,15 @@ __device__ __forceinline__ int d4gs_depth_bucket(float depth, uint32_t zmin_bits
   return k < nb ? k : nb - 1;
 }
 
+// The exposure blend's adjoint (blend.hip k_blend_bwd) folded into the composite backward's prologue by the one-call path (frame.hip):
+// a pixel of sub-sample s takes v_blended / S on the mean channels, the whole of it on a max / min channel iff s is the first
+// sub-sample (of the first S - 1) whose value equals the blended one, and v_acc / S on alpha - k_blend_bwd's expressions, bit for bit.
+struct BlendAdj {
+  const float *v_blended;  // [H,W,channels] or NULL
+  const float *v_acc;      // [H,W] or NULL
+  const float *blended;    // [H,W,channels] the blended frame (winner test)
+  uint64_t non_mean;       // bit c: channel c is a max / min channel
+};
 bool d4gs_lazy_on(const D4gsDims *d, const D4gsProjOut *out);
 int d4gs_lazy_pivot_launch(const D4gsDims *d, const D4gsProjOut *out, int64_t near_target, hipStream_t stream);
 int d4gs_lazy_far_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream);

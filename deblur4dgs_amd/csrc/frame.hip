@@ -10,7 +10,7 @@ int d4gs_project_fwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOu
 int d4gs_bin_sort_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, hipStream_t);
 int d4gs_raster_fwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, const D4gsRaster *, hipStream_t);
 int d4gs_raster_bwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect *, const D4gsRaster *,
-                         const D4gsRasterGrads *, hipStream_t);
+                         const D4gsRasterGrads *, const BlendAdj *, hipStream_t);
 int d4gs_project_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, const float *, const float *,
                           const float *, const float *, const float *, const D4gsLeafGrads *, hipStream_t);
 int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *,
@@ -149,7 +149,21 @@ int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO 
   FrameBufs b = carve(dims, isect_capacity, ws);
   bind_io(b, io, isect_capacity, max_tile_hint);
   const float *v_renders = g->v_renders, *v_alphas = g->v_alphas;
-  if (io->blended) {
+  // The blend's adjoint rides in the composite backward's prologue (common.h BlendAdj) unless the caller also holds gradients on the
+  // sub-sample images themselves: no k_blend_bwd launch, no [S,H,W,channels] gradient stack written and read back.
+  // D4GS_FUSE_BLEND_BWD=0: the separate kernel (A/B; same bits).
+  static const bool fuse_env = []() { const char *e = getenv("D4GS_FUSE_BLEND_BWD"); return !(e && e[0] == '0'); }();
+  const int nch_all = dims->D + (dims->depth_mode != D4GS_DEPTH_NONE ? 1 : 0);
+  // (narrow renders only: the 17-channel composite backward sits at its register budget - with the blend prologue it ran 1 018 -> 1 086 us
+  // on the reference's training shape, more than the 42 us k_blend_bwd costs there; profiles/r04t_ab_blend_bwd.txt)
+  const bool fuse_blend = fuse_env && io->blended && !g->v_renders && !g->v_alphas && dims->D <= 5;
+  BlendAdj ba{};
+  if (fuse_blend) {
+    ba.v_blended = g->v_blended, ba.v_acc = g->v_acc, ba.blended = io->blended;
+    for (int c = 0; c < nch_all; c++)
+      if (io->policy && io->policy[c] != 0) ba.non_mean |= (uint64_t)1 << c;
+    v_renders = nullptr, v_alphas = nullptr;
+  } else if (io->blended) {
     const int nch = dims->D + (dims->depth_mode != D4GS_DEPTH_NONE ? 1 : 0);
     // (gradients the caller holds on the sub-sample images themselves are summed in by the same kernel)
     if ((rc = d4gs_blend_bwd_add_impl(dims->S, (int64_t)dims->width * dims->height, nch, io->policy, io->renders, io->blended,
@@ -168,7 +182,7 @@ int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO 
     d4gs_set_error("d4gs_backward: fused statistics need vis_count, max_radii and a positive batch size");
     return D4GS_EINVAL;
   }
-  if ((rc = d4gs_raster_bwd_impl(dims, &b.proj, &b.isect, &b.raster, &rg, stream))) return rc;
+  if ((rc = d4gs_raster_bwd_impl(dims, &b.proj, &b.isect, &b.raster, &rg, fuse_blend ? &ba : nullptr, stream))) return rc;
   D4gsLeafGrads lg = *leaf;
   lg.partials = b.partials;
   return d4gs_project_bwd_impl(dims, in, &b.proj, g->v_means2d, b.v_conics, b.v_depths, b.v_opac_act, b.v_ctab, &lg, stream);

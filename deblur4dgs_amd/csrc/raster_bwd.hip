@@ -45,6 +45,8 @@ struct RasterBwdArgs {
   const int64_t *n_dev;  // device {total, longest list}; the lists were sized for (cap, max_hint) - see binning.hip
   int64_t cap, max_hint;
   const float *seg_state;  // SEG instantiations: the forward's per-pixel state at the depth-segment boundaries (common.h)
+  int fuse_blend;          // 1: v_out / v_alphas are not given - the pixel's gradients come from the blended frame's (`blend`)
+  BlendAdj blend;
 #ifdef D4GS_TRACE  // A/B builds only (scripts/trace_wgs.py): per-workgroup {start, end} wall clock, hardware id, list entries
   unsigned long long *trace;
 #endif
@@ -175,10 +177,33 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
     last = a.last_ids[pix];
     const float al = a.alphas[pix];
     const float Tfin = a.final_T[pix];
-    const float *vp = a.v_out + pix * NCH;
+    float v_al;
+    if (a.fuse_blend) {  // (workgroup-uniform) the exposure blend's adjoint, k_blend_bwd's arithmetic
+      const size_t P = (size_t)a.height * a.width, pb = (size_t)y * a.width + x;
+      const float inv = 1.f / (float)a.S;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) vo[c] = vp[c];
-    float v_al = a.v_alphas ? a.v_alphas[pix] : 0.f;
+      for (int c = 0; c < NCH; c++) {
+        const float g = a.blend.v_blended ? a.blend.v_blended[pb * NCH + c] : 0.f;
+        float v = g * inv;
+        if (((a.blend.non_mean >> c) & 1) && a.S > 1) {
+          const float o = a.blend.blended[pb * NCH + c];
+          int winner = -1;  // -1: the mean receives the gradient
+          for (int s2 = 0; s2 + 1 < a.S; s2++)
+            if (a.out[((size_t)s2 * P + pb) * NCH + c] == o) {
+              winner = s2;
+              break;
+            }
+          if (winner >= 0) v = s == winner ? g : 0.f;
+        }
+        vo[c] = v;
+      }
+      v_al = a.blend.v_acc ? a.blend.v_acc[pb] / (float)a.S : 0.f;
+    } else {
+      const float *vp = a.v_out + pix * NCH;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) vo[c] = vp[c];
+      v_al = a.v_alphas ? a.v_alphas[pix] : 0.f;
+    }
     if (DEPTH && a.ed) {
       const float den = fmaxf(al, 1e-10f);
       const float vd = vo[D];
@@ -792,8 +817,10 @@ int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, 
 }  // namespace
 
 int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
-                         const D4gsRasterGrads *g, hipStream_t stream) {
+                         const D4gsRasterGrads *g, const BlendAdj *blend, hipStream_t stream) {
   RasterBwdArgs a;
+  a.fuse_blend = blend != nullptr;
+  a.blend = blend ? *blend : BlendAdj{};
   a.N = dims->N, a.S = dims->S, a.width = dims->width, a.height = dims->height;
   a.tw = (dims->width + D4GS_TILE - 1) / D4GS_TILE;
   a.th = (dims->height + D4GS_TILE - 1) / D4GS_TILE;
