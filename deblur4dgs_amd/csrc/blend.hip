@@ -15,8 +15,11 @@ struct Policy {
   int8_t p[64];
 };
 
+// `win` (optional, [P][C] bytes): for the max / min channels, the sub-sample k_blend_bwd's first-match rule would hand the gradient to
+// (-1: the mean) - the one-call backward reads it instead of re-deriving it from the S - 1 renders (frame.hip, BlendAdj)
+template <bool WIN>
 __global__ void __launch_bounds__(256) k_blend_fwd(int S, int64_t P, int C, const Policy policy, const float *renders,
-                                                   const float *alphas, float *out, float *acc) {
+                                                   const float *alphas, float *out, float *acc, int8_t *win) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t PC = P * C;
   if (i < PC) {
@@ -26,12 +29,25 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int S, int64_t P, int C, cons
     const float mean = (S == 1) ? renders[i] : sum / (float)S;
     float v = mean;
     const int pol = policy.p[c];
+    // (best, w): the extreme raw value and the FIRST sub-sample that attains it - if the blended value equals it, that is the
+    // sub-sample k_blend_bwd's first-match rule hands the gradient to
+    float best = 0.f;
+    int w = -1;
     if (pol == 1) {
-      for (int s = 0; s + 1 < S; s++) v = fmaxf(v, renders[s * PC + i]);
+      for (int s = 0; s + 1 < S; s++) {
+        const float r = renders[s * PC + i];
+        v = fmaxf(v, r);
+        if (WIN && (w < 0 || r > best)) best = r, w = s;
+      }
     } else if (pol == 2) {
-      for (int s = 0; s + 1 < S; s++) v = fminf(v, renders[s * PC + i]);
+      for (int s = 0; s + 1 < S; s++) {
+        const float r = renders[s * PC + i];
+        v = fminf(v, r);
+        if (WIN && (w < 0 || r < best)) best = r, w = s;
+      }
     }
     out[i] = v;
+    if (WIN && pol != 0) win[i] = (int8_t)((w >= 0 && best == v) ? w : -1);
   }
   if (i < P) {
     float sum = 0.f;
@@ -178,7 +194,7 @@ __global__ void __launch_bounds__(256) k_shard_bwd(const ShardArgs a, const floa
 }  // namespace
 
 int d4gs_blend_fwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, const float *renders,
-                        const float *alphas, float *out, float *acc, hipStream_t stream) {
+                        const float *alphas, float *out, float *acc, int8_t *win, hipStream_t stream) {
   const int64_t n = P * C;
   Policy pol;
   if (C > 64 || C <= 0) {
@@ -186,8 +202,10 @@ int d4gs_blend_fwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, 
     return D4GS_EINVAL;
   }
   for (int c = 0; c < 64; c++) pol.p[c] = (c < C && policy) ? (int8_t)policy[c] : 0;
-  D4GS_LAUNCH("k_blend_fwd", k_blend_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders,
-                     alphas, out, acc);
+  if (win)
+    D4GS_LAUNCH("k_blend_fwd", k_blend_fwd<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders, alphas, out, acc, win);
+  else
+    D4GS_LAUNCH("k_blend_fwd", k_blend_fwd<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders, alphas, out, acc, win);
   return d4gs_check_launch("k_blend_fwd");
 }
 

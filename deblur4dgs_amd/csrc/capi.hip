@@ -20,7 +20,7 @@ int d4gs_control_stats_impl(int32_t, int32_t, const float *, const int32_t *, in
                             int64_t *, float *, int32_t, hipStream_t);
 int d4gs_control_plan_impl(int32_t, const uint8_t *, const uint8_t *, int32_t *, int32_t *, hipStream_t);
 int d4gs_gather_rows_impl(const int32_t *, int64_t, int32_t, const float *, float *, int64_t, int64_t, float, hipStream_t);
-int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *,
+int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *, int8_t *,
                         hipStream_t);
 int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
                         const float *, float *, float *, hipStream_t);
@@ -361,7 +361,7 @@ int d4gs_gather_rows(const int32_t *src_map, int64_t n_out, int32_t row_floats, 
 
 int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy, const float *renders,
                    const float *alphas, float *out, float *acc, void *stream) {
-  return d4gs_blend_fwd_impl(S, n_pixels, C, policy, renders, alphas, out, acc, (hipStream_t)stream);
+  return d4gs_blend_fwd_impl(S, n_pixels, C, policy, renders, alphas, out, acc, nullptr, (hipStream_t)stream);
 }
 
 int d4gs_blend_bwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy, const float *renders,

@@ -360,11 +360,11 @@ __device__ __forceinline__ int d4gs_depth_bucket(float depth, uint32_t zmin_bits
 
 // The exposure blend's adjoint (blend.hip k_blend_bwd) folded into the composite backward's prologue by the one-call path (frame.hip):
 // a pixel of sub-sample s takes v_blended / S on the mean channels, the whole of it on a max / min channel iff s is the first
-// sub-sample (of the first S - 1) whose value equals the blended one, and v_acc / S on alpha - k_blend_bwd's expressions, bit for bit.
+// sub-sample (of the first S - 1) whose value equals the blended one (k_blend_fwd leaves that index), and v_acc / S on alpha - k_blend_bwd's expressions, bit for bit.
 struct BlendAdj {
   const float *v_blended;  // [H,W,channels] or NULL
   const float *v_acc;      // [H,W] or NULL
-  const float *blended;    // [H,W,channels] the blended frame (winner test)
+  const int8_t *win;       // [H,W,channels] max / min channels: the sub-sample the gradient goes to, -1 = the mean (k_blend_fwd)
   uint64_t non_mean;       // bit c: channel c is a max / min channel
 };
 bool d4gs_lazy_on(const D4gsDims *d, const D4gsProjOut *out);

@@ -13,7 +13,7 @@ int d4gs_raster_bwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect 
                          const D4gsRasterGrads *, const BlendAdj *, hipStream_t);
 int d4gs_project_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, const float *, const float *,
                           const float *, const float *, const float *, const D4gsLeafGrads *, hipStream_t);
-int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *,
+int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *, int8_t *,
                         hipStream_t);
 int d4gs_blend_bwd_add_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
                             const float *, float *, float *, const float *, const float *, hipStream_t);
@@ -38,6 +38,7 @@ struct FrameBufs {
   D4gsRaster raster;
   float *v_renders, *v_alphas, *isect_grad, *v_conics, *v_depths, *v_opac_act, *v_ctab, *partials;
   uint8_t *isect_live;
+  int8_t *blend_win;  // [H*W][channels] who takes the gradient of a max / min channel (k_blend_fwd -> the composite backward's prologue)
   size_t bytes;      // the whole workspace
   size_t fwd_bytes;  // its prefix d4gs_forward uses (the backward scratch follows)
 };
@@ -58,6 +59,7 @@ FrameBufs carve(const D4gsDims *d, int64_t cap, void *ws) {
   b.isect.sorted_gid = c.take<int32_t>(m), b.isect.sorted_emit = c.take<int32_t>(m);
   b.raster.last_ids = c.take<int32_t>(z.last_ids), b.raster.final_T = c.take<float>(z.final_T);
   b.raster.seg_state = z.seg_state > 0 ? c.take<float>(z.seg_state) : nullptr;  // few-tile launches: depth-segment boundary states
+  b.blend_win = c.take<int8_t>((size_t)(z.render_colors / (d->S > 0 ? d->S : 1)));
   b.fwd_bytes = (c.off + 255) & ~(size_t)255;
   // backward scratch
   b.v_renders = c.take<float>(z.render_colors), b.v_alphas = c.take<float>(z.render_alphas);
@@ -128,7 +130,7 @@ int d4gs_forward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *
   if (io->blended) {
     const int nch = dims->D + (dims->depth_mode != D4GS_DEPTH_NONE ? 1 : 0);
     rc = d4gs_blend_fwd_impl(dims->S, (int64_t)dims->width * dims->height, nch, io->policy, io->renders, io->alphas, io->blended,
-                             io->acc, stream);
+                             io->acc, dims->D <= 5 ? b.blend_win : nullptr, stream);  // (the map is for the folded adjoint: narrow renders)
   }
   return rc;
 }
@@ -159,7 +161,7 @@ int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO 
   const bool fuse_blend = fuse_env && io->blended && !g->v_renders && !g->v_alphas && dims->D <= 5;
   BlendAdj ba{};
   if (fuse_blend) {
-    ba.v_blended = g->v_blended, ba.v_acc = g->v_acc, ba.blended = io->blended;
+    ba.v_blended = g->v_blended, ba.v_acc = g->v_acc, ba.win = b.blend_win;
     for (int c = 0; c < nch_all; c++)
       if (io->policy && io->policy[c] != 0) ba.non_mean |= (uint64_t)1 << c;
     v_renders = nullptr, v_alphas = nullptr;

@@ -179,20 +179,14 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
     const float Tfin = a.final_T[pix];
     float v_al;
     if (a.fuse_blend) {  // (workgroup-uniform) the exposure blend's adjoint, k_blend_bwd's arithmetic
-      const size_t P = (size_t)a.height * a.width, pb = (size_t)y * a.width + x;
+      const size_t pb = (size_t)y * a.width + x;
       const float inv = 1.f / (float)a.S;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const float g = a.blend.v_blended ? a.blend.v_blended[pb * NCH + c] : 0.f;
         float v = g * inv;
         if (((a.blend.non_mean >> c) & 1) && a.S > 1) {
-          const float o = a.blend.blended[pb * NCH + c];
-          int winner = -1;  // -1: the mean receives the gradient
-          for (int s2 = 0; s2 + 1 < a.S; s2++)
-            if (a.out[((size_t)s2 * P + pb) * NCH + c] == o) {
-              winner = s2;
-              break;
-            }
+          const int winner = a.blend.win[pb * NCH + c];  // -1: the mean receives the gradient
           if (winner >= 0) v = s == winner ? g : 0.f;
         }
         vo[c] = v;
