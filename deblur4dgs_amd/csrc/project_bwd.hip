@@ -658,6 +658,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float *partials, 
   const int b0 = blockIdx.y * per, b1 = min(b0 + per, n_blocks);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int b = b0;
+#pragma unroll 4  // (sixteen rows in flight; the order of the additions is unchanged)
   for (; b + 3 < b1; b += 4) {
     a0 += partials[(size_t)b * n + o];
     a1 += partials[(size_t)(b + 1) * n + o];
@@ -683,6 +684,7 @@ __global__ void __launch_bounds__(256) k_finish(const BwdArgs a, const float *re
     for (int o = threadIdx.x; o < n; o += 256) {
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       int b = 0;
+#pragma unroll 4
       for (; b + 3 < n_in; b += 4) {
         a0 += red_in[(size_t)b * n + o];
         a1 += red_in[(size_t)(b + 1) * n + o];

@@ -472,13 +472,26 @@ __global__ void __launch_bounds__(1024) k_scan_single(const ScanJob ja, const Sc
   __syncthreads();
   int64_t carry = 0;
   int vmax = 0;
-  for (int64_t base = 0; base < n; base += blockDim.x) {
-    int64_t i = base + threadIdx.x;
-    int v = i < n ? in[i] + (in2 ? in2[i] : 0) : 0;
-    vmax = max(vmax, v);
+  // eight consecutive items per thread and round.  (This kernel's time - 12 / 41 / 84 us on cfg2 / cfg3 / cfg5 - is NOT its rounds: one
+  // item per thread, 57 rounds on cfg5, measured the same.  It grows with the tile count because its first loads wait for k_count_tiles'
+  // device-scope atomics on the same counters to drain: the backlog of the kernel in front is charged here.)
+  constexpr int SI = 8;
+  for (int64_t base = 0; base < n; base += (int64_t)blockDim.x * SI) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * SI;
+    int v[SI], sum = 0;
+#pragma unroll
+    for (int j = 0; j < SI; j++) {
+      v[j] = i0 + j < n ? in[i0 + j] + (in2 ? in2[i0 + j] : 0) : 0;
+      vmax = max(vmax, v[j]);
+      sum += v[j];
+    }
     int tot;
-    int ex = block_exclusive_scan(v, &tot, lds);
-    if (i < n) out[i] = (int)(carry + ex);
+    int64_t run = carry + block_exclusive_scan(sum, &tot, lds);
+#pragma unroll
+    for (int j = 0; j < SI; j++) {
+      if (i0 + j < n) out[i0 + j] = (int)run;
+      run += v[j];
+    }
     carry += tot;
   }
   if (max64) {
