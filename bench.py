@@ -417,7 +417,7 @@ def main():
     graph_note = {}
 
     def measured_peaks():
-        """SURVEY 8d / BASELINE.md section 4: the ceilings are MEASURED on this box, before the timed region - a ~1 GiB
+        """SURVEY 8d / BASELINE.md section 4: the ceilings are MEASURED on this box, in the same process as the timed region (after it) - a ~1 GiB
         device-to-device stream copy and an FMA issue loop (d4gs_measure_peaks, csrc/peaks.hip; ~30 ms of device time)."""
         try:
             scratch = torch.empty(1 << 31, dtype=torch.uint8, device=dev)  # 2 x 1 GiB: far beyond the 256 MB MALL
@@ -432,14 +432,13 @@ def main():
                 return None
             return {"hbm_stream_copy_gbs": out[0], "fp32_pk_fma_tflops": out[1], "fp32_fma_tflops": out[2],
                     "copy_bytes_per_launch": out[3],
-                    "how": "d4gs_measure_peaks on this GPU right before the timed region: device-to-device float4 stream copy of 1 GiB "
+                    "how": "d4gs_measure_peaks on this GPU right after the timed region: device-to-device float4 stream copy of 1 GiB "
                            "(non-temporal, 8 loads in flight per lane, 256 workgroups per CU; read + write bytes / best of 8 launches), v_pk_fma_f32 and v_fma_f32 issue loops at 8 waves per SIMD "
                            "(16 independent chains per lane, best of 5)"}
         except Exception as e:  # the ceilings are context, not the measurement: never take the bench line down
             sys.stderr.write(f"d4gs_measure_peaks failed: {e!r}\n")
             return None
 
-    peaks = measured_peaks() if rank == 0 and not dry and not args.no_peaks else None
 
     def measure(mode, steps, warmup, profile):
         """-> (seconds for `steps` steps: max over ranks, live kernel timings, last state)"""
@@ -667,6 +666,8 @@ def main():
         n_isect = st.n_isect
         S_loc = st.cfg.S
         out["n_isect_per_step"] = n_isect if world == 1 else None
+        # (after every timed region: ~30 ms of full-rate FMA issue right in front of one cost it 0.2 % - 1.4052 against 1.4024 ms, four runs each)
+        peaks = measured_peaks() if not args.no_peaks else None
         out["peaks_measured"] = peaks
         if kern:
             per = {k: v[1] / n_break for k, v in sorted(kern_all.items(), key=lambda kv: -kv[1][1])}
