@@ -540,7 +540,9 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
                     host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
                 if host_n is None:
                     host_n = torch.empty(4, dtype=torch.int64).pin_memory()
-                host_n.copy_(n_isect_dev(), non_blocking=True)
+                # (a kernel stores the counts into the pinned buffer: a device-to-host copy here is a DMA-engine trip the backward's
+                # kernels would wait for)
+                L.check(L.lib().d4gs_copy_counts(L.ptr(n_isect_dev()), host_n.data_ptr(), raw_stream(dev.index)), "copy_counts")
                 ev = torch.cuda.Event()
                 ev.record()
                 with _SIZE_LOCK:

@@ -133,8 +133,9 @@ int main() {
   void *ws;
   HIP(hipMalloc(&ws, ws_bytes));
   D4(d4gs_forward(&dims, &in_d, &io_d, ws, ws_bytes, cap, 0, stream));
-  int64_t g_n[4];
-  D4(d4gs_copy_counts(d_n, g_n, stream));  // (pageable memory here: the copy is simply synchronous)
+  int64_t *g_n;  // pinned: d4gs_copy_counts is a kernel that stores the counts into host memory the device can address
+  HIP(hipHostMalloc((void **)&g_n, 4 * sizeof(int64_t), hipHostMallocDefault));
+  D4(d4gs_copy_counts(d_n, g_n, stream));
   HIP(hipStreamSynchronize(stream));
   if (g_n[0] > cap) {
     fprintf(stderr, "list capacity %lld too small for %lld intersections\n", (long long)cap, (long long)g_n[0]);

@@ -206,8 +206,10 @@ const char *d4gs_last_error(void);
  * out[1] = fp32 TFLOP/s with v_pk_fma_f32, out[2] = fp32 TFLOP/s with v_fma_f32 (what the composite kernels issue), out[3] = bytes
  * copied per launch.  Diagnostic: creates its own HIP events and WAITS for them - not for timed regions or stream captures. */
 int d4gs_measure_peaks(void *scratch /* device, >= 64 MiB */, size_t scratch_bytes, double *out /* [host] [4] */, void *stream);
-/* D4gsProjOut.n_isect -> pinned host memory, as ONE asynchronous copy on `stream` (hipMemcpyAsync; a memcpy node when the stream
- * is being captured - how a step replayed from a HIP graph keeps reporting its list sizes: engine.GraphWatch). */
+/* D4gsProjOut.n_isect -> PINNED (device-addressable: hipHostMalloc / torch pin_memory) host memory, by a one-wave kernel on `stream`
+ * that stores the four counts there (a kernel node when the stream is being captured - how a step replayed from a HIP graph keeps
+ * reporting its list sizes: engine.GraphWatch; a device-to-host copy node would hold up the kernels behind it).  Read the buffer after
+ * an event recorded behind this call has completed. */
 int d4gs_copy_counts(const int64_t *n_isect /* device [4] */, int64_t *host_pinned /* [4] */, void *stream);
 size_t d4gs_scan_ws_elems(int64_t n_instances);
 size_t d4gs_bwd_partials_elems(const D4gsDims *dims);
