@@ -37,7 +37,9 @@ for P in (1, 2, 4, 8):
     for v in leaves.values():
         v.grad = None
     times.grad = RTs.grad = None
-    with torch.cuda.graph(g):
+    import contextlib
+    watch = engine.GraphWatch() if os.environ.get("SHARD_WATCH") else None  # (SHARD_WATCH=1: what the size-reporting node costs a replay)
+    with (watch.capturing() if watch else contextlib.nullcontext()), torch.cuda.graph(g):
         step_g = step  # (deferred checks are skipped under capture)
         step_g()
     for _ in range(3):
