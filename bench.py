@@ -63,6 +63,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pre-roll", type=int, default=30,
+                    help="untimed steps BEFORE the warm-up steps (reported in config.pre_roll_steps): the first ~10 steps of a process run "
+                         "3-7 %% slow (list-size guesses, row mode and lazy-sort decisions settle within 3; the device then needs ~15 ms of "
+                         "load to reach its sustained state - profiles/r04t_bench_ramp.txt), so with a short --warmup the mean of K timed "
+                         "steps is the start-up ramp, not the frame time a training run sees")
     ap.add_argument("--config", default="cfg2", choices=list(CONFIGS))
     ap.add_argument("--shard", default="exposure", choices=["exposure", "views"])
     ap.add_argument("--channels", type=int, default=None, choices=[3, 16],
@@ -415,6 +420,7 @@ def main():
         return got
 
     graph_note = {}
+    step_stats = {}
 
     def measured_peaks():
         """SURVEY 8d / BASELINE.md section 4: the ceilings are MEASURED on this box, in the same process as the timed region (after it) - a ~1 GiB
@@ -489,8 +495,14 @@ def main():
                 engine.check_deferred()  # this step's list sizes, verified behind its launches (raises on overflow)
 
         eager_step = step
-        for _ in range(warmup):
+        n_pre = (0 if dry else args.pre_roll) + warmup
+        for i in range(n_pre):
+            if profile and i == max(n_pre - 2, 0):
+                lib.d4gs_profile_enable(3)  # the event machinery's first use (a one-off of up to 1.4 ms) happens here, not in the timed region
             step()
+        if profile and n_pre:
+            sync()
+            collect()  # (discarded: the timed region starts from empty records)
         sync()
         if args.graph:  # same kernels, same arithmetic; one hipGraphLaunch per step.  The sharded step is captured with its
             # RCCL collectives (verified at world size 1 only: tests/test_gpu_parallel.py - the pool has 1-GPU boxes).
@@ -588,12 +600,20 @@ def main():
             if not captured and sharder is not None:
                 sharder.deferred_size_check = deferred
         if profile:
-            lib.d4gs_profile_enable(2)  # HIP events around the rasterization kernels only: timing EVERY kernel costs two
-        t0 = time.perf_counter()      # stream events per launch, ~0.12 ms of a 1.6 ms frame
+            lib.d4gs_profile_enable(3)  # HIP events around the roofline's kernel - the composite backward - only: timing EVERY
+        t0 = time.perf_counter()      # kernel costs two stream events per launch, ~0.12 ms of a 1.6 ms frame
+        marks = []
         for _ in range(steps):
             step()
+            marks.append(time.perf_counter())  # (host time a step's calls returned: says WHERE a slow run lost its time)
         sync()
         dt = time.perf_counter() - t0
+        host_gaps = [b - a for a, b in zip([t0] + marks[:-1], marks)]
+        step_stats["host_ms_median"] = 1e3 * sorted(host_gaps)[len(host_gaps) // 2]
+        step_stats["host_ms_max"] = 1e3 * max(host_gaps)
+        step_stats["host_ms_max_at"] = host_gaps.index(max(host_gaps))
+        step_stats["slowest"] = [(i, round(1e3 * g, 4)) for g, i in sorted(((g, i) for i, g in enumerate(host_gaps)), reverse=True)[:5]]
+        step_stats["last_sync_ms"] = 1e3 * (t0 + dt - marks[-1])
         kern, kern_all, n_break = {}, {}, 0
         if profile:
             kern = collect()  # the dominant kernels, measured live over the timed region
@@ -666,6 +686,8 @@ def main():
         n_isect = st.n_isect
         S_loc = st.cfg.S
         out["n_isect_per_step"] = n_isect if world == 1 else None
+        out["config"]["pre_roll_steps"] = args.pre_roll
+        out["host_step_times"] = dict(step_stats, note="per-step host time between the returns of consecutive steps inside the timed region (diagnostic)")
         # (after every timed region: ~30 ms of full-rate FMA issue right in front of one cost it 0.2 % - 1.4052 against 1.4024 ms, four runs each)
         peaks = measured_peaks() if not args.no_peaks else None
         out["peaks_measured"] = peaks

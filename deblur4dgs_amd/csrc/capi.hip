@@ -57,7 +57,7 @@ struct ProfRec {
   const char *name;
   hipEvent_t a, b;
 };
-int g_prof_on = 0;  // 0 off, 1 every kernel, 2 only the rasterization kernels (k_raster*)
+int g_prof_on = 0;  // 0 off, 1 every kernel, 2 only the rasterization kernels (k_raster*), 3 only the composite backward (k_raster_bwd*)
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
 }  // namespace
@@ -65,6 +65,7 @@ std::mutex g_prof_mu;
 ProfScope::ProfScope(const char *name, hipStream_t s) : slot(-1), stream(s) {
   if (!g_prof_on) return;
   if (g_prof_on == 2 && strncmp(name, "k_raster", 8) != 0) return;
+  if (g_prof_on == 3 && strncmp(name, "k_raster_bwd", 12) != 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.name = name;

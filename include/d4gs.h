@@ -196,7 +196,8 @@ typedef struct D4gsLeafGrads {
 int d4gs_version(void);
 /* optional per-kernel HIP-event timing (bench.py's roofline object): enable, run, then collect
  * "kernel_name launches total_ms" lines.  on = 1 times every kernel (two stream events per launch: ~0.12 ms per
- * cfg2 frame), on = 2 only the rasterization kernels (k_raster*, what the roofline object needs), 0 = off (default; no
+ * cfg2 frame), on = 2 only the rasterization kernels (k_raster*), on = 3 only the composite backward (k_raster_bwd*: what bench.py's
+ * roofline object needs from its timed region), 0 = off (default; no
  * events are created). */
 void d4gs_profile_enable(int on);
 int d4gs_profile_collect(char *buf /* [host] */, size_t cap);
