@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pre-roll", type=int, default=30,
-                    help="untimed steps BEFORE the warm-up steps (reported in config.pre_roll_steps): the first ~10 steps of a process run "
+                    help="untimed steps between the warm-up steps (+ the graph capture, if any) and the timed region (reported in config.pre_roll_steps): the first ~10 steps of a process run "
                          "3-7 %% slow (list-size guesses, row mode and lazy-sort decisions settle within 3; the device then needs ~15 ms of "
                          "load to reach its sustained state - profiles/r04t_bench_ramp.txt), so with a short --warmup the mean of K timed "
                          "steps is the start-up ramp, not the frame time a training run sees")
@@ -495,14 +495,8 @@ def main():
                 engine.check_deferred()  # this step's list sizes, verified behind its launches (raises on overflow)
 
         eager_step = step
-        n_pre = (0 if dry else args.pre_roll) + warmup
-        for i in range(n_pre):
-            if profile and i == max(n_pre - 2, 0):
-                lib.d4gs_profile_enable(3)  # the event machinery's first use (a one-off of up to 1.4 ms) happens here, not in the timed region
+        for _ in range(warmup):
             step()
-        if profile and n_pre:
-            sync()
-            collect()  # (discarded: the timed region starts from empty records)
         sync()
         if args.graph:  # same kernels, same arithmetic; one hipGraphLaunch per step.  The sharded step is captured with its
             # RCCL collectives (verified at world size 1 only: tests/test_gpu_parallel.py - the pool has 1-GPU boxes).
@@ -599,6 +593,17 @@ def main():
                     step = eager_step
             if not captured and sharder is not None:
                 sharder.deferred_size_check = deferred
+        # pre-roll: untimed steps of the FINAL step function (eager, or the replay of the graph captured above - capturing leaves the
+        # device idle for a while) right in front of the timed region, so that it starts from the sustained state (--pre-roll)
+        n_pre = 0 if dry else args.pre_roll
+        for i in range(n_pre):
+            if profile and i == max(n_pre - 2, 0):
+                lib.d4gs_profile_enable(3)  # the event machinery's first use (a one-off of up to 1.4 ms) happens here, not in the timed region
+            step()
+        if n_pre:
+            sync()
+            if profile:
+                collect()  # (discarded: the timed region starts from empty records)
         if profile:
             lib.d4gs_profile_enable(3)  # HIP events around the roofline's kernel - the composite backward - only: timing EVERY
         t0 = time.perf_counter()      # kernel costs two stream events per launch, ~0.12 ms of a 1.6 ms frame
