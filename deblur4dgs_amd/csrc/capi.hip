@@ -128,6 +128,16 @@ int d4gs_copy_counts(const int64_t *n_isect, int64_t *host_pinned, void *stream)
     d4gs_set_error("d4gs_copy_counts: NULL argument");
     return D4GS_EINVAL;
   }
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, host_pinned) != hipSuccess || at.type != hipMemoryTypeHost) {
+    (void)hipGetLastError();  // pageable memory: the device cannot address it - an ordinary (for pageable memory: synchronous) copy
+    hipError_t e = hipMemcpyAsync(host_pinned, n_isect, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) {
+      d4gs_set_error("d4gs_copy_counts: %s", hipGetErrorString(e));
+      return D4GS_ELAUNCH;
+    }
+    return D4GS_OK;
+  }
   D4GS_LAUNCH("k_copy_counts", k_copy_counts, dim3(1), dim3(64), 0, (hipStream_t)stream, n_isect, host_pinned);
   return d4gs_check_launch("k_copy_counts");
 }

@@ -210,7 +210,7 @@ int d4gs_measure_peaks(void *scratch /* device, >= 64 MiB */, size_t scratch_byt
 /* D4gsProjOut.n_isect -> PINNED (device-addressable: hipHostMalloc / torch pin_memory) host memory, by a one-wave kernel on `stream`
  * that stores the four counts there (a kernel node when the stream is being captured - how a step replayed from a HIP graph keeps
  * reporting its list sizes: engine.GraphWatch; a device-to-host copy node would hold up the kernels behind it).  Read the buffer after
- * an event recorded behind this call has completed. */
+ * an event recorded behind this call has completed.  (Pageable memory is accepted too: it gets an ordinary device-to-host copy.) */
 int d4gs_copy_counts(const int64_t *n_isect /* device [4] */, int64_t *host_pinned /* [4] */, void *stream);
 size_t d4gs_scan_ws_elems(int64_t n_instances);
 size_t d4gs_bwd_partials_elems(const D4gsDims *dims);

@@ -155,3 +155,24 @@ def test_no_grad_render_takes_the_forward_workspace_only_and_the_cold_call_only_
     (r_g["blended"].sum()).backward()  # and the differentiable one still has its scratch
     torch.cuda.synchronize()
     assert float(lv["means"].grad.abs().sum()) > 0
+
+
+def test_copy_counts_into_pinned_and_pageable_memory():
+    """d4gs_copy_counts stores the four counts into PINNED host memory from a kernel (no copy node for the kernels behind it to wait
+    for); a pageable buffer - which the device cannot address - still gets them, through an ordinary copy."""
+    import ctypes as C
+
+    import numpy as np
+
+    from deblur4dgs_amd import _lib as L
+
+    dev = torch.device("cuda:0")
+    lib = L.lib()
+    src = torch.tensor([123456789012, 4321, 77, 5], dtype=torch.int64, device=dev)
+    pinned = torch.zeros(4, dtype=torch.int64).pin_memory()
+    pageable = np.zeros(4, dtype=np.int64)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.d4gs_copy_counts(C.c_void_p(src.data_ptr()), C.c_void_p(pinned.data_ptr()), stream) == 0
+    assert lib.d4gs_copy_counts(C.c_void_p(src.data_ptr()), C.c_void_p(pageable.ctypes.data), stream) == 0
+    torch.cuda.synchronize()
+    assert pinned.tolist() == [123456789012, 4321, 77, 5] and pageable.tolist() == [123456789012, 4321, 77, 5]
