@@ -24,8 +24,12 @@ def _render(L, K, W, H, fused, blend=True, D=3, **kw):
                            return_depth=True, blend=blend, fused=fused, **kw)
 
 
+@pytest.mark.parametrize("sub_losses", [True, False])
 @pytest.mark.parametrize("N,G,K_,S,W,H,D", [(5000, 3000, 4, 3, 160, 96, 3), (800, 0, 1, 1, 64, 48, 3), (3000, 3000, 12, 5, 96, 64, 16)])
-def test_one_call_path_equals_the_staged_chain_bitwise(N, G, K_, S, W, H, D):
+def test_one_call_path_equals_the_staged_chain_bitwise(N, G, K_, S, W, H, D, sub_losses):
+    """sub_losses=False: gradients arrive on the blended frame and its accumulation only - d4gs_backward then folds the blend's adjoint
+    into the composite backward's prologue (renders of <= 5 colour channels; the max / min channel's winner comes from k_blend_fwd's
+    map) instead of launching k_blend_bwd, which the staged chain always does: the two must still agree bit for bit."""
     dev = torch.device("cuda:0")
     sc = make_scene(N, G, max(K_, 1), S, W, H, seed=31)
     K = sc["K"].to(dev)
@@ -40,7 +44,9 @@ def test_one_call_path_equals_the_staged_chain_bitwise(N, G, K_, S, W, H, D):
         r = _render(L, K, W, H, fused, D=D)
         assert bool(r["state"].frame_io) == fused
         # losses on the blurry frame, its accumulation AND the per-sub-sample images (flow3d/trainer.py:575-618)
-        loss = (r["blended"] * wb).sum() + (r["acc"] * wa).sum() + (r["renders"] * ws).sum() + (r["alphas"] * wsa).sum()
+        loss = (r["blended"] * wb).sum() + (r["acc"] * wa).sum()
+        if sub_losses:
+            loss = loss + (r["renders"] * ws).sum() + (r["alphas"] * wsa).sum()
         xys = None
         if fused:
             xys = [r["means2d"][s:s + 1].detach().requires_grad_() for s in range(S)]
