@@ -1,0 +1,35 @@
+"""bench.py's contract with the driver, checked on the device: ONE JSON line on stdout with the metric of BASELINE.json, the whole-job value,
+and the `roofline` and `cpu_baseline` objects (measurement section of the task: bound / achieved / peak / unit / frac / traffic; value / unit /
+cores / kind / sample)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_default_bench_line_carries_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--pre-roll", "3"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["unit"] == "Gaussians/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["metric"].startswith("Gaussians/s fwd+bwd, 288x512, N_exposure=8") and "Gaussians/s fwd+bwd" in base["metric"]
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["scaling"] in ("weak", "strong")
+    assert "cfg2" in d["config"]["workload"] and d["config"]["pre_roll_steps"] == 3 and "model" not in d["config"]
+    assert abs(d["value"] - 300000 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]  # whole-job throughput = N / frame time
+    assert 0.5 < d["ms_per_step"] < 10.0
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and roof["peak"] > 0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and "traffic" in roof and roof["kernel"].startswith("k_raster_bwd")
+    assert roof["avg_launch_ms"] > 0 and roof["peak_measured"] > 0  # the kernel's live duration and the box's measured ceiling
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["unit"] == "Gaussians/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert d["value"] > 100 * cpu["value"]  # (a reported baseline, not a target: only that both legs measured the same thing)
