@@ -97,7 +97,7 @@ RAW_PARAMS, RAW_COLORS, EXACT_CULL, LAZY_SORT = 1, 2, 4, 8
 DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
 ROWS_AUTO, ROWS_DENSE, ROWS_SPARSE = 0, 1, 2
 TILE = 16
-VERSION = 303  # D4GS_VERSION of include/d4gs.h
+VERSION = 304  # D4GS_VERSION of include/d4gs.h
 GEOM_STRIDE = 8
 
 EXPORTS = (

@@ -15,11 +15,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libd4gs.so")
+# the linker keeps `d4gs_*` and drops the rest from the dynamic symbol table (libstdc++ template instantiations and hipcc's
+# __hip_cuid_* markers are emitted with default visibility whatever -fvisibility says)
+LINK = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "libd4gs.map")]
 # A/B build for the tests only: the same sources with -DD4GS_VARIANTS, which adds the non-default composite kernels
 # (csrc/variants/*.inc, selected by D4GS_{FWD,BWD}_* environment variables).  Never loaded by the package itself.
 VARIANTS_LIB = os.path.join(HERE, "..", "tests", "libd4gs_variants.so")
 VARIANT_SOURCES = ("raster_fwd.hip", "raster_bwd.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: only the D4GS_API entry points of include/d4gs.h are exported (tests/test_c_abi.py checks `nm -D`).  No
+# -munsafe-fp-atomics: the library issues no floating-point atomics at all (the gradient reductions are deterministic gathers).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # per-file extras.  project_bwd: the SLP vectorizer turns the adjoint chain into v_pk_* math, which is not faster on gfx950 (4.5
 # cycles for two operations against 2.5 for one) and parks ~40 duplicated operands in VGPR pairs: 256 + 30 registers instead of 128
 FILE_FLAGS = {"project_bwd.hip": ["-fno-slp-vectorize"]}
@@ -66,7 +71,7 @@ def build(force: bool = False, extra: list[str] | None = None) -> str:
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, extra), srcs))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [*LINK, "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
@@ -81,7 +86,7 @@ def build_variants() -> str:
     for s in _sources():
         objs.append(_compile(s, ["-DD4GS_VARIANTS"], ".var.o") if s in VARIANT_SOURCES else os.path.join(OBJ, s.replace(".hip", ".o")))
     if not os.path.exists(VARIANTS_LIB) or any(os.path.getmtime(o) > os.path.getmtime(VARIANTS_LIB) for o in objs):
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", VARIANTS_LIB, *objs], capture_output=True, text=True)
+        r = subprocess.run([*LINK, "-o", VARIANTS_LIB, *objs], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
     return VARIANTS_LIB
@@ -103,7 +108,7 @@ def build_ab(name: str, src: str, defines: list[str]) -> str:
         ab[one] = obj
     objs = [ab.get(s) or os.path.join(OBJ, s.replace(".hip", ".o")) for s in _sources()]
     lib = os.path.join(out_dir, f"libd4gs_{name}.so")
-    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+    r = subprocess.run([*LINK, "-o", lib, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     return lib

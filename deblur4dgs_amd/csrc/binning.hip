@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
     for (int z = tid; z < tiles; z += EMIT_THREADS) {
       int p = a.lazy.pivot[tbase + z];
       if (LZ == 2) {
-        if (a.lazy.flag[tbase + z]) {
+        if (a.lazy.flag[tbase + z] == 1) {  // (2: an earlier d4gs_raster_fwd on these lists emitted + sorted that far part)
           const int ty = z / a.tw, tx = z - ty * a.tw;
           atomicMin(&fbox[0], tx), atomicMin(&fbox[1], ty), atomicMax(&fbox[2], tx), atomicMax(&fbox[3], ty);
         } else {
@@ -365,7 +365,7 @@ __device__ __forceinline__ bool lazy_range(const SortArgs &a, int t, int &base, 
   if (a.pass == 1) n = min(n, a.lazy_near[t]);
   else if (a.pass == 2) {
     const int nn = a.lazy_near[t];
-    if (nn >= n || !a.lazy_flag[t]) return false;
+    if (nn >= n || a.lazy_flag[t] != 1) return false;
     base += nn, n -= nn;
   }
   return true;

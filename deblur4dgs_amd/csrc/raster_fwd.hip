@@ -141,9 +141,13 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   int end = a.tile_offsets[t + 1];
   const int end_full = end;
   bool has_far = false;  // workgroup-uniform
+  // lazy_flag[t]: 0 - the near part was enough (so far), 1 - pass 1 found the tile unsaturated: its far part is to be emitted and
+  // sorted, 2 - that has been done (by an earlier d4gs_raster_fwd over the same binning: the channel chunks of a wide render share the
+  // lists, and the far keys must be emitted exactly once).  A tile flagged by an earlier call goes straight to pass 2.
   if (a.lazy_pass == 1) {
     const int nn = a.lazy_near[t];
     has_far = nn < end - start;
+    if (has_far && a.lazy_flag[t]) return;
     end = min(end, start + nn);
   } else if (a.lazy_pass == 2 && !a.lazy_flag[t]) return;
   const size_t inst_base = (size_t)s * a.N;
@@ -263,6 +267,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       return;
     }
   }
+  if (a.lazy_pass == 2 && tid == 0) a.lazy_flag[t] = 2;  // (workgroup t is the only reader and writer of flag[t] in this launch)
   if constexpr (SEG) seg_store(0);
 
   // live-row sample (include/d4gs.h, D4gsProjOut.n_isect[2..3]): every `stride`-th tile adds its list length and the entries

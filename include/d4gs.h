@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define D4GS_VERSION 303
+/* libd4gs.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table. */
+#define D4GS_API __attribute__((visibility("default")))
+
+#define D4GS_VERSION 304
 #define D4GS_TILE 16
 #define D4GS_GEOM_STRIDE 8 /* floats per instance record: x, y, opacity, depth, conic a, b, c, pad */
 
@@ -193,27 +196,27 @@ typedef struct D4gsLeafGrads {
   float *partials;       /* [d4gs_bwd_partials_elems(dims)] scratch for the deterministic 2-level reduction */
 } D4gsLeafGrads;
 
-int d4gs_version(void);
+D4GS_API int d4gs_version(void);
 /* optional per-kernel HIP-event timing (bench.py's roofline object): enable, run, then collect
  * "kernel_name launches total_ms" lines.  on = 1 times every kernel (two stream events per launch: ~0.12 ms per
  * cfg2 frame), on = 2 only the rasterization kernels (k_raster*), on = 3 only the composite backward (k_raster_bwd*: what bench.py's
  * roofline object needs from its timed region), 0 = off (default; no
  * events are created). */
-void d4gs_profile_enable(int on);
-int d4gs_profile_collect(char *buf /* [host] */, size_t cap);
-const char *d4gs_last_error(void);
+D4GS_API void d4gs_profile_enable(int on);
+D4GS_API int d4gs_profile_collect(char *buf /* [host] */, size_t cap);
+D4GS_API const char *d4gs_last_error(void);
 /* The two MEASURED device ceilings bench.py quotes its roofline fractions against: a device-to-device stream copy over
  * `scratch` (first half -> second half, best of 8) and an FMA issue loop at 8 waves per SIMD.  out[0] = copy GB/s (read + write),
  * out[1] = fp32 TFLOP/s with v_pk_fma_f32, out[2] = fp32 TFLOP/s with v_fma_f32 (what the composite kernels issue), out[3] = bytes
  * copied per launch.  Diagnostic: creates its own HIP events and WAITS for them - not for timed regions or stream captures. */
-int d4gs_measure_peaks(void *scratch /* device, >= 64 MiB */, size_t scratch_bytes, double *out /* [host] [4] */, void *stream);
+D4GS_API int d4gs_measure_peaks(void *scratch /* device, >= 64 MiB */, size_t scratch_bytes, double *out /* [host] [4] */, void *stream);
 /* D4gsProjOut.n_isect -> PINNED (device-addressable: hipHostMalloc / torch pin_memory) host memory, by a one-wave kernel on `stream`
  * that stores the four counts there (a kernel node when the stream is being captured - how a step replayed from a HIP graph keeps
  * reporting its list sizes: engine.GraphWatch; a device-to-host copy node would hold up the kernels behind it).  Read the buffer after
  * an event recorded behind this call has completed.  (Pageable memory is accepted too: it gets an ordinary device-to-host copy.) */
-int d4gs_copy_counts(const int64_t *n_isect /* device [4] */, int64_t *host_pinned /* [4] */, void *stream);
-size_t d4gs_scan_ws_elems(int64_t n_instances);
-size_t d4gs_bwd_partials_elems(const D4gsDims *dims);
+D4GS_API int d4gs_copy_counts(const int64_t *n_isect /* device [4] */, int64_t *host_pinned /* [4] */, void *stream);
+D4GS_API size_t d4gs_scan_ws_elems(int64_t n_instances);
+D4GS_API size_t d4gs_bwd_partials_elems(const D4gsDims *dims);
 
 /* Element counts of every caller-allocated buffer for one configuration (the "workspace query" of SURVEY 8b): the
  * per-instance / per-tile buffers of D4gsProjOut, the image buffers of D4gsRaster, and - per intersection, to be
@@ -229,25 +232,25 @@ typedef struct {
   int64_t lazy_ws;                                               /* D4gsProjOut.lazy_ws (int32 elements; needed with D4GS_LAZY_SORT only) */
   int32_t tiles_x, tiles_y, channels;                            /* tile grid; D + depth channel */
 } D4gsSizes;
-int d4gs_query_sizes(const D4gsDims *dims, D4gsSizes *sizes);
+D4GS_API int d4gs_query_sizes(const D4gsDims *dims, D4gsSizes *sizes);
 
 /* a1-a6 + projection + tile counting + scans.  Replaces params.py:39-43,142-180, transforms.py:41-53,
  * scene_model.py:67-120,352-353 and gsplat fully_fused_projection_fwd + isect_tiles pass 1 for all S. */
-int d4gs_project_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, void *stream);
+D4GS_API int d4gs_project_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *out, void *stream);
 
 /* isect_tiles pass 2 + per-tile depth sort (replaces gsplat isect_tiles / radix sort / isect_offset_encode). */
-int d4gs_bin_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, void *stream);
+D4GS_API int d4gs_bin_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, void *stream);
 
 /* rasterize_to_pixels_fwd for all S sub-samples (+ expected-depth normalisation when depth_mode == ED). */
-int d4gs_raster_fwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
+D4GS_API int d4gs_raster_fwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
                     void *stream);
 
 /* rasterize_to_pixels_bwd + per-instance gather of the per-intersection gradients (deterministic, no float atomics). */
-int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
+D4GS_API int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, const D4gsRaster *r,
                     const D4gsRasterGrads *g, void *stream);
 
 /* fully_fused_projection_bwd + deformation / activation adjoints for all S, reduced to leaf gradients. */
-int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *proj,
+D4GS_API int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjOut *proj,
                      const float *v_means2d, const float *v_conics, const float *v_depths, const float *v_opac_act,
                      const float *v_ctab, const D4gsLeafGrads *grads, void *stream);
 
@@ -256,8 +259,8 @@ int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
  * in->means, motion_coefs, rots, transls, times (= target_ts), RTs (= target_w2cs[:, :3, :], may be NULL), viewmat,
  * Kmat; every other input may be NULL.  The backward fills v_means, v_motion_coefs, v_rots, v_transls, v_times,
  * v_RTs, v_viewmat of D4gsLeafGrads (the other leaf pointers are not touched). */
-int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points /* [S,N,3] */, void *stream);
-int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points /* [S,N,3] */,
+D4GS_API int d4gs_points_fwd(const D4gsDims *dims, const D4gsProjIn *in, float *points /* [S,N,3] */, void *stream);
+D4GS_API int d4gs_points_bwd(const D4gsDims *dims, const D4gsProjIn *in, const float *v_points /* [S,N,3] */,
                     const D4gsLeafGrads *grads, void *stream);
 
 /* a4/a5 pose API of the S2 seam (flow3d/scene_model.py:58-120; called by the reference's Trainer at
@@ -277,8 +280,8 @@ typedef struct D4gsPoses {
   float *transforms;  /* [S,G,3,4] | [G,S,3,4] */
   int32_t g_major;
 } D4gsPoses;
-int d4gs_poses_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *out, void *stream);
-int d4gs_poses_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *v_out, const D4gsLeafGrads *grads,
+D4GS_API int d4gs_poses_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *out, void *stream);
+D4GS_API int d4gs_poses_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *v_out, const D4gsLeafGrads *grads,
                    void *stream);
 
 /* Densification statistics, Trainer._prepare_control_step (flow3d/trainer.py:953-990) for one render of
@@ -287,7 +290,7 @@ int d4gs_poses_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsPoses *
  *   max_radii[g] = max(max_radii[g], radii[s,g] / max(W, H))  -- ONLY when update_max_radii != 0: the reference
  *   computes this maximum and then drops it (out-of-place `index_put`, trainer.py:987-989), so its `max_radii`
  *   stays at its initial value; 0 reproduces that.   Running stats are updated in place. */
-int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad /* [S,N,2] */, const int32_t *radii /* [S,N] */,
+D4GS_API int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad /* [S,N,2] */, const int32_t *radii /* [S,N] */,
                        int32_t width, int32_t height, int32_t batch_size, float *grad_norm_acc /* [N] */,
                        int64_t *vis_count /* [N] */, float *max_radii /* [N] */, int32_t update_max_radii,
                        void *stream);
@@ -301,9 +304,9 @@ int d4gs_control_stats(int32_t S, int32_t N, const float *xys_grad /* [S,N,2] */
  * of `row_floats` 32-bit words per row; rows >= zero_from are zero-filled (new Adam moments: zero_from = n_keep), rows
  * >= add_from get `add` added (split halves of `scales`: add_from = n_keep + n_dup, add = -log 1.6); pass INT64_MAX
  * to disable either. */
-int d4gs_control_plan(int32_t N, const uint8_t *split_or_cull, const uint8_t *dup, int32_t *src_map, int32_t *counts,
+D4GS_API int d4gs_control_plan(int32_t N, const uint8_t *split_or_cull, const uint8_t *dup, int32_t *src_map, int32_t *counts,
                       void *stream);
-int d4gs_gather_rows(const int32_t *src_map, int64_t n_out, int32_t row_floats, const float *in, float *out,
+D4GS_API int d4gs_gather_rows(const int32_t *src_map, int64_t n_out, int32_t row_floats, const float *in, float *out,
                      int64_t zero_from, int64_t add_from, float add, void *stream);
 
 /* a12 camera path: the generator of `RTs [S,3,4]` / `times [S]` that feed d4gs_project_fwd.
@@ -315,22 +318,22 @@ int d4gs_gather_rows(const int32_t *src_map, int64_t n_out, int32_t row_floats, 
  * delta0/delta1 [6] are the two MLP head outputs.  jac [S,12,12] = d RTs[s,i] / d (delta0|delta1)[j] (NULL to skip),
  * dtimes [S] = d times / d time_params[index], deltaT [2] = {|half-width|, its derivative}.  The backward is the
  * mat-vec v_delta = v_RTs . jac plus the time_params row (v_* inputs may be NULL = zero). */
-int d4gs_camera_path_fwd(const float *delta0, const float *delta1, int32_t S, const float *time_params,
+D4GS_API int d4gs_camera_path_fwd(const float *delta0, const float *delta1, int32_t S, const float *time_params,
                          int32_t n_time_params, int32_t index, float t, float *RTs /* [S,3,4] */,
                          float *jac /* [S,12,12] */, float *times /* [S] */, float *dtimes /* [S] */,
                          float *deltaT /* [2] */, void *stream);
-int d4gs_camera_path_bwd(const float *jac, const float *dtimes, const float *deltaT, const float *v_RTs,
+D4GS_API int d4gs_camera_path_bwd(const float *jac, const float *dtimes, const float *deltaT, const float *v_RTs,
                          const float *v_times, const float *v_deltaT, int32_t S, int32_t index,
                          int32_t n_time_params, float *v_delta0 /* [6] */, float *v_delta1 /* [6] */,
                          float *v_time_params /* [n_time_params] */, void *stream);
 /* MoveModel.preprocessPose + positional embedding (move_model.py:12-63,104-110; spline_utils.py:177-195):
  * R [3,3] with row stride r_stride (4 for the top-left block of a [4,4] w2c), T [3] with element stride t_stride
  * -> enc [66] = [x, sin(x f), cos(x f)]_{f=1,2,4,8,16}, x = SE3_to_se3([R|T]). */
-int d4gs_pose_encode(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc /* [66] */,
+D4GS_API int d4gs_pose_encode(const float *R, int32_t r_stride, const float *T, int32_t t_stride, float *enc /* [66] */,
                      void *stream);
 /* Its input gradient (test-time pose refinement differentiates the render w.r.t. w2c, which also feeds the
  * MoveModel: flow3d/validator.py:442-448 -> flow3d/scene_model.py:249-256): v_enc [66] -> v_R [3,3] dense, v_T [3]. */
-int d4gs_pose_encode_bwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const float *v_enc,
+D4GS_API int d4gs_pose_encode_bwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const float *v_enc,
                          float *v_R /* [9] */, float *v_T /* [3] */, void *stream);
 
 /* The whole MoveModel (move_model.py:66-166) for one pose, one call each way: d4gs_pose_encode -> the 9-layer MLP
@@ -360,9 +363,9 @@ typedef struct {
   float *v_delta;       /* [12] scratch */
   float *v_enc;         /* [66] gradient of the pose encoding (input of d4gs_pose_encode_bwd), or NULL to skip */
 } D4gsMoveModelGrads;
-int d4gs_move_model_fwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const D4gsMoveModelParams *p,
+D4GS_API int d4gs_move_model_fwd(const float *R, int32_t r_stride, const float *T, int32_t t_stride, const D4gsMoveModelParams *p,
                         int32_t S, int32_t index, float t, int32_t stage_first, const D4gsMoveModelOut *out, void *stream);
-int d4gs_move_model_bwd(const D4gsMoveModelParams *p, const D4gsMoveModelOut *out, const float *v_RTs,
+D4GS_API int d4gs_move_model_bwd(const D4gsMoveModelParams *p, const D4gsMoveModelOut *out, const float *v_RTs,
                         const float *v_times, const float *v_deltaT, int32_t S, int32_t index,
                         const D4gsMoveModelGrads *grads, void *stream);
 
@@ -372,19 +375,19 @@ int d4gs_move_model_bwd(const D4gsMoveModelParams *p, const D4gsMoveModelOut *ou
  * pred, gt [B,H,W,3] channel-last; mask [B,H,W] or NULL.  Forward: loss[3] = {loss, l1, ssim} (device), plus what the
  * backward needs: maps [B,H-10,W-10,3,3], partials [d4gs_photometric_blocks(B,H,W), 2] scratch.  Backward:
  * v_pred [B,H,W,3] = dL/dpred * v_loss[0] (v_loss is a device scalar). */
-int64_t d4gs_photometric_blocks(int32_t B, int32_t H, int32_t W);
-int d4gs_photometric_fwd(const float *pred, const float *gt, const float *mask, int32_t B, int32_t H, int32_t W, int32_t C,
+D4GS_API int64_t d4gs_photometric_blocks(int32_t B, int32_t H, int32_t W);
+D4GS_API int d4gs_photometric_fwd(const float *pred, const float *gt, const float *mask, int32_t B, int32_t H, int32_t W, int32_t C,
                          float w_l1, float w_ssim, float *maps, float *partials, float *loss, void *stream);
-int d4gs_photometric_bwd(const float *pred, const float *gt, const float *mask, const float *maps, const float *v_loss,
+D4GS_API int d4gs_photometric_bwd(const float *pred, const float *gt, const float *mask, const float *maps, const float *v_loss,
                          int32_t B, int32_t H, int32_t W, int32_t C, float w_l1, float w_ssim, float *v_pred,
                          void *stream);
 
 /* a9 exposure blend (scene_model.py:386-397): out = mean_S; policy[c] 1 -> max over {raw_0..raw_{S-2}, mean},
  * 2 -> min over the same set (the reference's in-place quirk); acc = mean_S alphas. */
-int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] [C] */,
+D4GS_API int d4gs_blend_fwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] [C] */,
                    const float *renders /* [S,P,C] */, const float *alphas /* [S,P] */, float *out /* [P,C] */,
                    float *acc /* [P] */, void *stream);
-int d4gs_blend_bwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] */, const float *renders,
+D4GS_API int d4gs_blend_bwd(int32_t S, int64_t n_pixels, int32_t C, const int32_t *policy /* [host] */, const float *renders,
                    const float *out, const float *v_out, const float *v_acc, float *v_renders /* [S,P,C] */,
                    float *v_alphas /* [S,P] */, void *stream);
 
@@ -418,14 +421,14 @@ typedef struct D4gsFrameGrads {
   float *stats_max_radii;
   int32_t stats_batch_size, stats_update_max_radii, row_mode;
 } D4gsFrameGrads;
-size_t d4gs_frame_workspace_bytes(const D4gsDims *dims, int64_t isect_capacity);
+D4GS_API size_t d4gs_frame_workspace_bytes(const D4gsDims *dims, int64_t isect_capacity);
 /* The prefix of that workspace d4gs_forward alone touches (everything but the backward's scratch: image-gradient stack, per-
  * intersection gradient rows, per-instance gradients, block partials - roughly half): a forward that will never be followed by
  * d4gs_backward (validation, viewer) may pass a workspace of this size. */
-size_t d4gs_frame_workspace_bytes_fwd(const D4gsDims *dims, int64_t isect_capacity);
-int d4gs_forward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, void *workspace, size_t ws_bytes,
+D4GS_API size_t d4gs_frame_workspace_bytes_fwd(const D4gsDims *dims, int64_t isect_capacity);
+D4GS_API int d4gs_forward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, void *workspace, size_t ws_bytes,
                  int64_t isect_capacity, int64_t max_tile_hint, void *stream);
-int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, const D4gsFrameGrads *g,
+D4GS_API int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, const D4gsFrameGrads *g,
                   const D4gsLeafGrads *leaf /* .partials is ignored: it lives in the workspace */, void *workspace,
                   size_t ws_bytes, int64_t isect_capacity, int64_t max_tile_hint, void *stream);
 
@@ -433,8 +436,8 @@ int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO 
  * and the same structs with every pointer a HOST pointer; no stream, no workspace (scratch is allocated and freed inside; the
  * backward re-runs the forward), io->n_isect [4] host.  Scalar fp32, one thread - a separate entry point for hosts without a
  * GPU, never a fallback: d4gs_forward and the Python seams still refuse CPU tensors.  csrc/cpu_twin.hip. */
-int d4gs_forward_cpu(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io);
-int d4gs_backward_cpu(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, const D4gsFrameGrads *g,
+D4GS_API int d4gs_forward_cpu(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io);
+D4GS_API int d4gs_backward_cpu(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *io, const D4gsFrameGrads *g,
                       const D4gsLeafGrads *leaf);
 
 /* Exposure sharding (one process per GPU): the same blend when this process holds only the sub-samples
@@ -449,14 +452,14 @@ typedef struct D4gsShardBlend {
   int64_t n_pixels;
   const int32_t *policy; /* [host] [C] */
 } D4gsShardBlend;
-int d4gs_blend_shard_partial_fwd(const D4gsShardBlend *b, const float *renders /* [S_local,P,C] */,
+D4GS_API int d4gs_blend_shard_partial_fwd(const D4gsShardBlend *b, const float *renders /* [S_local,P,C] */,
                                  const float *alphas /* [S_local,P] */, float *part /* [P,C+1] */, float *cand /* [P,npol] */,
                                  void *stream);
-int d4gs_blend_shard_finish_fwd(const D4gsShardBlend *b, const float *part, const float *cand, float *out /* [P,C] */,
+D4GS_API int d4gs_blend_shard_finish_fwd(const D4gsShardBlend *b, const float *part, const float *cand, float *out /* [P,C] */,
                                 float *acc /* [P] */, void *stream);
-int d4gs_blend_shard_winner(const D4gsShardBlend *b, const float *renders, const float *out, int32_t *win /* [P,npol] */,
+D4GS_API int d4gs_blend_shard_winner(const D4gsShardBlend *b, const float *renders, const float *out, int32_t *win /* [P,npol] */,
                             void *stream);
-int d4gs_blend_shard_bwd(const D4gsShardBlend *b, const float *v_out, const float *v_acc /* or NULL */, const int32_t *win,
+D4GS_API int d4gs_blend_shard_bwd(const D4gsShardBlend *b, const float *v_out, const float *v_acc /* or NULL */, const int32_t *win,
                          float *v_renders /* [S_local,P,C] */, float *v_alphas /* [S_local,P] */, void *stream);
 
 #ifdef __cplusplus

@@ -29,10 +29,24 @@ def test_exports_match_header(lib):
         assert hasattr(lib, n), f"{n} declared in d4gs.h but not exported"
 
 
+def test_dynamic_symbol_table_is_exactly_the_header(lib):
+    """`nm -D`: the library exports the C entry points of include/d4gs.h and nothing else - no mangled C++ internals, no libstdc++
+    template instantiations (-fvisibility=hidden + the linker version script csrc/libd4gs.map).  Both the product library and the
+    tests' A/B build."""
+    import subprocess
+
+    from deblur4dgs_amd import build
+
+    for path in (build.LIB, build.build_variants()):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        syms = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+        assert syms == _declared(), (path, sorted(set(syms) ^ set(_declared())))
+
+
 def test_version_and_error_paths(lib):
     from deblur4dgs_amd import _lib as L
 
-    assert lib.d4gs_version() == 303
+    assert lib.d4gs_version() == 304
     lib.d4gs_last_error.restype = C.c_char_p
     assert lib.d4gs_project_fwd(None, None, None, None) == -1  # D4GS_EINVAL, no HIP call made
     assert b"NULL" in lib.d4gs_last_error()

@@ -625,7 +625,10 @@ def test_depth_segmented_backward_equals_the_whole_list_replay(mode, D, opaque, 
 
 
 @pytest.mark.parametrize("mode,D,kind", [("RGB+ED", 3, "opaque"), ("RGB+ED", 3, "translucent"), ("RGB", 8, "mixed"), ("RGB+ED", 16, "opaque"),
-                                         ("RGB+ED", 3, "opaque_long"), ("RGB+ED", 3, "mixed_long")])
+                                         ("RGB+ED", 3, "opaque_long"), ("RGB+ED", 3, "mixed_long"),
+                                         # two / three channel chunks over ONE binning (engine.channel_chunks): every chunk's d4gs_raster_fwd
+                                         # runs both lazy passes, the far keys must be emitted and sorted by the first one only
+                                         ("RGB+ED", 32, "opaque"), ("RGB", 37, "mixed"), ("RGB+ED", 20, "translucent")])
 def test_lazy_far_sort_changes_nothing_but_the_dead_tails(mode, D, kind):
     """D4GS_LAZY_SORT (include/d4gs.h): every tile list is partitioned at emit time into the nearest depth buckets (~ near_target keys) and
     the rest; near parts are sorted and composited first, the far part only for tiles that did not saturate inside the near part.
