@@ -69,7 +69,15 @@ def parse():
                          "load to reach its sustained state - profiles/r04t_bench_ramp.txt), so with a short --warmup the mean of K timed "
                          "steps is the start-up ramp, not the frame time a training run sees")
     ap.add_argument("--config", default="cfg2", choices=list(CONFIGS))
-    ap.add_argument("--shard", default="exposure", choices=["exposure", "views"])
+    ap.add_argument("--shard", default="auto", choices=["auto", "exposure", "views", "mesh"],
+                    help="N > 1: `exposure` = BASELINE config 4 (the S sub-samples of ONE frame over all ranks; strong scaling), `views` = one "
+                         "full frame of its own camera view per rank (data parallel; weak scaling), `mesh` = V views x E-way exposure "
+                         "(--mesh VxE).  `auto` (default): exposure at N = 2, mesh (N/2)x2 from N = 4 (N = 8: 4 views x 2-way exposure) - "
+                         "the line's secondary objects always carry the strict exposure-only and views-only numbers as well")
+    ap.add_argument("--mesh", default=None, metavar="VxE", help="with --shard mesh: V views x E-way exposure sharding, V * E == --gpus")
+    ap.add_argument("--graph-timeout", type=float, default=90.0,
+                    help="N > 1: seconds each phase after the first (eager) measurement may take - the HIP-graph capture / replays with RCCL "
+                         "collectives inside, the secondary measurements - before a watchdog prints the line measured so far and exits 0")
     ap.add_argument("--channels", type=int, default=None, choices=[3, 16],
                     help="colour channels before depth: 3 = RGB+ED (headline), 16 = the reference's dynamic-training "
                          "shape (rgb + mask + 4x3 track channels + depth = 17, scene_model.py:233-296; default of "
@@ -229,27 +237,28 @@ def _stats(ts, N, S):
             "instances_per_s": N * S / statistics.median(ts)}
 
 
-def _cpu_twin_cfg1(iters=5):
-    """BASELINE config 1 through the PRODUCT's CPU twin (d4gs_forward_cpu / d4gs_backward_cpu, scalar fp32, one thread) -
+def _cpu_twin(cfgname="cfg1", iters=5):
+    """A BASELINE config through the PRODUCT's CPU twin (d4gs_forward_cpu / d4gs_backward_cpu, scalar fp32, one thread) -
     reported beside the oracle's legs; it is product code, so it is not the checker and not `value`."""
     from deblur4dgs_amd.cpu_twin import render_exposure_cpu
 
-    N, G, K, S, W, H = CONFIGS["cfg1"]
-    sc = scene_of("cfg1", channels=3)
-    keys = ("means", "quats", "scales", "colors", "opacities")
+    N, G, K, S, W, H = CONFIGS[cfgname]
+    sc = scene_of(cfgname, channels=3)
+    keys = ("means", "quats", "scales", "colors", "opacities") + (("motion_coefs", "rots", "transls") if G > 0 else ())
     P = {k: sc[k].float().clone().requires_grad_() for k in keys}
     ts = []
     for _ in range(iters):
         for v in P.values():
             v.grad = None
         t0 = time.perf_counter()
-        r = render_exposure_cpu(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], 3, None, None, None, None,
+        r = render_exposure_cpu(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], 3, P.get("motion_coefs"), P.get("rots"),
+                                P.get("transls"), sc["times"].float() if G > 0 else None,
                                 sc["RTs"].float(), sc["viewmat"].float(), sc["K"].float(), W, H, background=torch.ones(3),
                                 return_depth=True)
         (r["blended"].sum() + r["acc"].sum()).backward()
         ts.append(time.perf_counter() - t0)
     out = _stats(ts, N, S)
-    out.update(cores=1, entry="d4gs_forward_cpu + d4gs_backward_cpu (csrc/cpu_twin.hip)", config="cfg1")
+    out.update(cores=1, entry="d4gs_forward_cpu + d4gs_backward_cpu (csrc/cpu_twin.hip)", config=cfgname)
     return out
 
 
@@ -261,11 +270,10 @@ def cpu_baseline(name, channels, full=False):
     with --cpu-baseline-full, committed under profiles/)."""
     host = os.cpu_count()
     out = {"unit": "Gaussians/s", "kind": "port", "cpu_model": _cpu_model(), "host_cores": host, "runs": {}}
-    # default run: scalar C only (cfg1 x 20 + the benched config x 3: ~20 s); the torch restatement is minutes per frame
-    # and belongs to the full plan, whose output is committed under profiles/
-    plan = [("cfg1", "scalar_c", 20)]
-    if full:
-        plan += [("cfg1", "torch", 20)]
+    # default run (BASELINE.md section 3, bounded to well under a minute of CPU work): scalar C on cfg1 x 20 + the benched config
+    # x 3, ONE frame of the torch restatement on cfg1 (16 threads; a cfg2 frame of it is minutes and stays in the full plan, committed
+    # under profiles/), and the product's own CPU twin on cfg1 x 5 and on cfg2 x 1
+    plan = [("cfg1", "scalar_c", 20), ("cfg1", "torch", 20 if full else 1)]
     if name != "cfg1":
         plan += [(name, "scalar_c", 3 if full or name in ("cfg2", "tiny", "refdefault") else 1)]
         if full:
@@ -286,15 +294,18 @@ def cpu_baseline(name, channels, full=False):
         if n_isect is not None:
             r["n_isect"] = n_isect
         out["runs"][f"{cfgname}/{impl}"] = r
-    out["product_cpu_twin"] = _cpu_twin_cfg1()
+    out["product_cpu_twin"] = _cpu_twin("cfg1", 5)
+    if name == "cfg2":
+        out["product_cpu_twin_cfg2"] = _cpu_twin("cfg2", 1)
     head = out["runs"][f"{name}/scalar_c"]
     N, G, K, S, W, H = CONFIGS[name]
     out.update(value=head["gaussians_per_s"], cores=head["cores"],
                sample=f"{head['iters']} full frame(s) of {name} ({N} Gaussians, {W}x{H}, S={S}), forward + backward through "
                       f"oracle/raster_ref.c (scalar C, fp32) with the {S} sub-samples on {head['cores']} parallel threads + torch "
                       f"deformation; median {head['s_per_frame_median']:.2f} s per frame (min {head['s_per_frame_min']:.2f}, max "
-                      f"{head['s_per_frame_max']:.2f}); `runs` holds cfg1 in full (20 iterations); the torch restatement's leg "
-                      f"of BASELINE.md section 3 runs with --cpu-baseline-full (profiles/r03_cpu_baseline_full.json)")
+                      f"{head['s_per_frame_max']:.2f}); `runs` also holds cfg1 in full (20 iterations of scalar C) and one cfg1 frame of the torch "
+                      f"restatement on {min(TORCH_CPU_THREADS, host)} threads; `product_cpu_twin[_cfg2]` = the product's own scalar CPU entry points; the "
+                      f"torch restatement on cfg2 (minutes per frame) runs with --cpu-baseline-full (profiles/r03_cpu_baseline_full.json)")
     return out
 
 
@@ -341,6 +352,83 @@ def _traffic(name, kernel):
     return {"fetch_1x": f, "fetch_2x": 2 * f, "write": w, "total_1x": f + w, "total_2x": 2 * f + w}
 
 
+class Watchdog:
+    """N > 1: the eager sharded step is measured FIRST; everything after it (the HIP-graph capture with RCCL collectives inside,
+    its replays, the secondary measurements) runs under this watchdog.  If a phase does not finish in time - a collective that hangs
+    in a capture is the realistic first-contact failure at N = 8, and RCCL's own watchdog takes 600 s and prints no line - rank 0
+    prints the line measured so far (`config.launch` says what happened) and every rank leaves with exit code 0.  A daemon thread:
+    torch's collectives, synchronize(), graph replay and .item() all release the GIL while they wait; `faulthandler` (a C thread that
+    needs no GIL) is the last resort behind it."""
+
+    def __init__(self, rank: int, timeout: float):
+        import threading
+
+        self.rank, self.timeout = rank, timeout
+        self.out = None  # the best line so far (rank 0)
+        self.phase = ""
+        self.deadline = None
+        self._lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def kick(self, phase: str, out=None):
+        """A phase starts: (re)arm the deadline; `out` replaces the line a firing watchdog prints."""
+        import faulthandler
+
+        with self._lock:
+            self.phase = phase
+            if out is not None:
+                self.out = json.loads(json.dumps(out))  # a private copy: the main thread keeps editing its own
+            self.deadline = time.monotonic() + self.timeout
+        faulthandler.dump_traceback_later(self.timeout + 30.0, exit=True)
+
+    def done(self):
+        import faulthandler
+
+        with self._lock:
+            self.deadline = None
+        faulthandler.cancel_dump_traceback_later()
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            with self._lock:
+                fire = self.deadline is not None and time.monotonic() > self.deadline
+                out, phase = self.out, self.phase
+            if fire:
+                if self.rank == 0 and out is not None:
+                    out.setdefault("config", {})["launch"] = (f"WATCHDOG: phase '{phase}' did not finish within {self.timeout:g} s (hung collective / "
+                                                              "capture?); this is the line measured before it (eager step)")
+                    out["watchdog_fired_in"] = phase
+                    os.write(1, (json.dumps(out) + "\n").encode())
+                sys.stderr.write(f"[bench.py rank {self.rank}] watchdog: phase '{phase}' timed out; leaving with the line measured so far\n")
+                sys.stderr.flush()
+                os._exit(0)
+
+
+def resolve_shard(args, world):
+    """-> (mode, (V, E)) of the primary measurement."""
+    if world == 1:
+        return ("exposure" if args.shard in ("auto", "mesh") else args.shard), (1, 1)
+    if args.shard == "exposure":
+        return "exposure", (1, world)
+    if args.shard == "views":
+        return "views", (world, 1)
+    if args.shard == "mesh":
+        if not args.mesh:
+            raise SystemExit("--shard mesh needs --mesh VxE")
+        V, E = (int(x) for x in args.mesh.lower().split("x"))
+        if V * E != world:
+            raise SystemExit(f"--mesh {args.mesh}: V * E must equal --gpus ({world})")
+        return "mesh", (V, E)
+    # auto: 2-way exposure sharding inside each view, the rest of the ranks as views (see DESIGN.md section 5)
+    if world == 2:
+        return "exposure", (1, 2)
+    if world % 2 == 0:
+        return "mesh", (world // 2, 2)
+    return "views", (world, 1)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -355,10 +443,12 @@ def main():
     dev = torch.device("cpu") if dry else torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
     # N > 1: the sharded step leaves each rank a fraction of a millisecond of device work behind ~1 ms of host launch work,
-    # so the captured step (one hipGraphLaunch, RCCL collectives inside) is the default there; --no-graph times the eager one
+    # so the captured step (one hipGraphLaunch, RCCL collectives inside) is the default there; --no-graph times the eager one.
+    # The EAGER step is measured first and its line kept; the capture and everything after it run under a watchdog (class Watchdog).
     graph_default = world > 1 and not args.graph and not args.no_graph
-    if graph_default:
-        args.graph = True
+    want_graph = args.graph or graph_default
+    eager_first = world > 1 and want_graph
+    primary_mode, primary_mesh = resolve_shard(args, world)
     if use_dist:
         import torch.distributed as dist
 
@@ -378,11 +468,22 @@ def main():
     name = "tiny" if dry else args.config
     N, G, K, S, W, H = CONFIGS[name]
     channels = args.channels or (16 if name.startswith("refdefault") else 3)
-    if use_dist and args.shard == "exposure" and world > S:
-        raise SystemExit(f"--shard exposure needs world_size <= S ({world} > {S})")
+    if use_dist and primary_mesh[1] > S:
+        raise SystemExit(f"exposure sharding needs its width <= S ({primary_mesh[1]} > {S})")
     bg = torch.ones(channels, device=dev)
     lib = None if dry else L.lib()
-    prof = not args.no_profile and not args.graph and not dry  # HIP events cannot bracket kernels inside a replayed graph
+    prof_ok = not args.no_profile and not dry
+    _groups = {}
+
+    def exposure_group(V, E):
+        """The exposure sub-group of this rank's view in a V x E mesh (dist.new_group is collective: made once per mesh, by every rank)."""
+        if E == 1 or V == 1:
+            return None  # E == 1: no blend collective; V == 1: the world group
+        if (V, E) not in _groups:
+            from deblur4dgs_amd.parallel import mesh_exposure_group
+
+            _groups[(V, E)] = mesh_exposure_group(world, rank, V, E)
+        return _groups[(V, E)]
 
     def sync():
         if use_dist:
@@ -419,9 +520,6 @@ def main():
             got[nm] = (int(cnt), float(ms))
         return got
 
-    graph_note = {}
-    step_stats = {}
-
     def measured_peaks():
         """SURVEY 8d / BASELINE.md section 4: the ceilings are MEASURED on this box, in the same process as the timed region (after it) - a ~1 GiB
         device-to-device stream copy and an FMA issue loop (d4gs_measure_peaks, csrc/peaks.hip; ~30 ms of device time)."""
@@ -446,10 +544,16 @@ def main():
             return None
 
 
-    def measure(mode, steps, warmup, profile):
-        """-> (seconds for `steps` steps: max over ranks, live kernel timings, last state)"""
-        views = use_dist and mode == "views"
-        sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=rank if views else 0, channels=channels,
+    def measure(mode, mesh, steps, warmup, profile, use_graph):
+        """One measurement of `mode` (mesh = (V, E)): warm-up, optional HIP-graph capture, pre-roll, the timed region.
+        -> dict(dt = seconds for `steps` steps (max over ranks), kern / kern_all / n_break = live kernel timings, st = last state,
+                graph_note, step_stats)"""
+        graph_note, step_stats = {}, {}
+        if use_graph:
+            profile = False  # HIP events cannot bracket kernels inside a replayed graph
+        V, E = mesh
+        view = (rank // E) if use_dist else 0  # ranks of one view render the same scene
+        sc, d, leaves, wimg, wacc = make_inputs(name, dev, seed_offset=view if V > 1 else 0, channels=channels,
                                                 scale_mul=args.scale_mul)
         if args.spatial_order:  # the product's control.spatial_order_step, applied to the synthetic scene (all Gaussians dynamic or all
             from deblur4dgs_amd.control import morton_permutation  # static in the BASELINE configs; refdefault: per set)
@@ -466,7 +570,10 @@ def main():
             for k in ("times", "RTs"):
                 if k in leaves:
                     leaves[k] = leaves[k][::args.share].detach().clone().requires_grad_()
-        sharder = ShardedExposure(world, rank, mode=mode) if use_dist else None
+        sharder = None
+        if use_dist:
+            sharder = (ShardedExposure(world, rank, mode="mesh", mesh=(V, E), exposure_group=exposure_group(V, E)) if mode == "mesh"
+                       else ShardedExposure(world, rank, mode=mode))
         if sharder is not None:
             sharder.fused = not args.staged
             if dry:
@@ -498,7 +605,7 @@ def main():
         for _ in range(warmup):
             step()
         sync()
-        if args.graph:  # same kernels, same arithmetic; one hipGraphLaunch per step.  The sharded step is captured with its
+        if use_graph:  # same kernels, same arithmetic; one hipGraphLaunch per step.  The sharded step is captured with its
             # RCCL collectives (verified at world size 1 only: tests/test_gpu_parallel.py - the pool has 1-GPU boxes).
             mode_flag["deferred"] = False  # one host-checked eager step: its state carries the exact list sizes
             if sharder is not None:
@@ -542,6 +649,8 @@ def main():
                     v.grad = None
             try:
                 if dry:  # (rank 0 of a dry run "cannot capture": the agreement below must send EVERY rank to the eager step)
+                    if os.environ.get("D4GS_BENCH_INJECT_HANG") == "graph" and rank == world - 1:
+                        time.sleep(1e6)  # tests/test_parallel_gloo.py: a rank that never comes back from its capture
                     if rank == 0:
                         raise RuntimeError("no HIP graphs in a CPU dry run")
                     captured = True
@@ -622,7 +731,7 @@ def main():
         kern, kern_all, n_break = {}, {}, 0
         if profile:
             kern = collect()  # the dominant kernels, measured live over the timed region
-        if profile or (args.graph and not args.no_profile and not dry):
+        if profile or (use_graph and prof_ok and not eager_first):
             n_break = min(steps, 10)  # untimed extra pass of EAGER steps with every kernel timed: the full per-kernel breakdown
             lib.d4gs_profile_enable(1)
             for _ in range(n_break):
@@ -647,52 +756,73 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, kern, kern_all, n_break, last["st"]
+        return dict(dt=dt, kern=kern, kern_all=kern_all, n_break=n_break, st=last["st"], graph_note=graph_note, step_stats=step_stats,
+                    graph_used=bool(use_graph and "fallback" not in graph_note))
 
-    dt, kern, kern_all, n_break, st = measure(args.shard, args.steps, args.warmup, prof)
-    views_primary = use_dist and args.shard == "views"
-    ms_step = 1e3 * dt / args.steps
-    value = (world if views_primary else 1) * N / (dt / args.steps)
-    metric = "Gaussians/s fwd+bwd, 288x512, N_exposure=8" if name == "cfg2" else f"Gaussians/s fwd+bwd ({name})"
-    out = {
-        "metric": metric, "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if views_primary else "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "dry-run (CPU / gloo control-flow check, no kernels)" if dry else "synthetic",
-        "config": {"workload": f"{name}: {N} Gaussians ({G} dynamic), {K} motion bases, {W}x{H}, N_exposure={S}, "
-                                f"{channels}+depth channels, fwd+bwd to all leaves"
-                                + (f", extents x{args.scale_mul:g}" if args.scale_mul != 1.0 else ""),
-                   "gaussians": N, "exposure_subsamples": S,
-                   "parallelism": "1 GPU" if world == 1 else
-                   (f"BASELINE cfg4: exposure sub-samples sharded x{world}, RCCL blend + gradient all-reduce"
-                    if not views_primary else f"views sharded x{world} (data parallel), RCCL gradient all-reduce")},
-        "instances_per_s": value * S,
-    }
-    lazy_on = bool(getattr(getattr(st, "cfg", None), "lazy_sort", False))
-    if args.lazy_sort:
-        out["config"]["workload"] += "; D4GS_LAZY_SORT"
-    # the library's default (D4GS_LAZY_SORT=auto) decides by the previous render's live-row fraction and list length; say what it did
-    out["config"]["lazy_sort"] = "forced on (--lazy-sort)" if args.lazy_sort else ("on (auto)" if lazy_on else "off (auto)") \
-        if os.environ.get("D4GS_LAZY_SORT", "auto") == "auto" else ("on" if lazy_on else "off")
-    if args.spatial_order:
-        out["config"]["workload"] += f"; Gaussians in Morton order ({args.spatial_order}; control.spatial_order_step)"
-    if args.share > 1:
-        out["metric"] = f"DIAGNOSTIC rank-0 share of {name} at world size {args.share} (no collectives), Gaussians / t"
-        out["config"]["workload"] += f"; ONLY sub-samples s % {args.share} == 0 rendered (--share)"
-    out["config"]["size_check"] = ("host waits for every render's intersection counts" if args.sync_size_check else
-                                   "intersection counts verified once per step behind the launches (deferred)")
-    if args.graph:
-        out["config"]["launch"] = graph_note.get("fallback") or (
-            "one HIP graph per step (render forward + backward" + (" + RCCL collectives" if use_dist else "")
-            + " captured, deferred size check)" + ("; default for N > 1, --no-graph times the eager step" if graph_default else ""))
-    if world > 1 and not views_primary:  # secondary: data-parallel over camera views (weak scaling), same protocol
-        dt_v, _, _, _, _ = measure("views", args.steps, args.warmup, False)
-        out["views_weak_scaling"] = {"value": world * N / (dt_v / args.steps), "unit": "Gaussians/s", "scaling": "weak",
-                                     "ms_per_step": 1e3 * dt_v / args.steps,
-                                     "note": "every rank renders its own full frame (one camera view per GPU), flat "
-                                             "gradient all-reduce; NOT BASELINE's cfg4"}
-    if rank == 0 and dry:
-        print(json.dumps(out))
-    elif rank == 0:
+    def parallelism_of(mode, mesh):
+        V, E = mesh
+        if world == 1:
+            return "1 GPU"
+        if mode == "exposure":
+            return f"BASELINE cfg4: exposure sub-samples of ONE frame sharded x{world}, RCCL blend + gradient all-reduce"
+        if mode == "views":
+            return f"views sharded x{world} (data parallel: one full frame per rank), RCCL gradient all-reduce"
+        return (f"mesh {V}x{E}: {V} camera views (data parallel) x {E}-way exposure sharding of each view's {S} sub-samples; RCCL blend "
+                f"all-reduce inside each view's {E}-rank group, gradient all-reduce over all {world} ranks")
+
+    def brief(res, mode, mesh):
+        """A secondary measurement as a small object."""
+        V = mesh[0]
+        t = res["dt"] / args.steps
+        return {"value": V * N / t, "unit": "Gaussians/s", "scaling": "strong" if V == 1 else "weak", "ms_per_step": 1e3 * t,
+                "frames_per_step": V, "parallelism": parallelism_of(mode, mesh),
+                "launch": ("one HIP graph per step" if res["graph_used"] else "eager") + (f" ({res['graph_note']['fallback']})" if res["graph_note"].get("fallback") else "")}
+
+    def line_of(res, mode, mesh):
+        """The JSON line of one measurement: the contract fields on every rank; rank 0 of a device run adds the roofline objects
+        (live kernel timings of `res` + the committed counter files)."""
+        dt, kern, kern_all, n_break, st = res["dt"], res["kern"], res["kern_all"], res["n_break"], res["st"]
+        graph_note, step_stats = res["graph_note"], res["step_stats"]
+        V = mesh[0] if use_dist else 1
+        ms_step = 1e3 * dt / args.steps
+        value = V * N / (dt / args.steps)  # whole job: V frames of N Gaussians per step
+        metric = "Gaussians/s fwd+bwd, 288x512, N_exposure=8" if name == "cfg2" else f"Gaussians/s fwd+bwd ({name})"
+        out = {
+            "metric": metric, "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if V == 1 else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "dry-run (CPU / gloo control-flow check, no kernels)" if dry else "synthetic",
+            "config": {"workload": f"{name}: {N} Gaussians ({G} dynamic), {K} motion bases, {W}x{H}, N_exposure={S}, "
+                                    f"{channels}+depth channels, fwd+bwd to all leaves"
+                                    + (f", extents x{args.scale_mul:g}" if args.scale_mul != 1.0 else ""),
+                       "gaussians": N, "exposure_subsamples": S, "frames_per_step": V,
+                       "parallelism": parallelism_of(mode, mesh)},
+            "instances_per_s": value * S,
+        }
+        if V > 1:
+            out["config"]["scaling_note"] = (f"{V} frames per step (one per camera view), each view's exposure sub-samples split {mesh[1]} ways: the "
+                                             "per-GPU work is fixed from N = 4 on (half a frame), so the contract's word is \"weak\"; the strict BASELINE "
+                                             "cfg4 number (ONE frame over all ranks, strong scaling) is the `exposure_strong_scaling` object of this line")
+        lazy_on = bool(getattr(getattr(st, "cfg", None), "lazy_sort", False))
+        if args.lazy_sort:
+            out["config"]["workload"] += "; D4GS_LAZY_SORT"
+        # the library's default (D4GS_LAZY_SORT=auto) decides by the previous render's live-row fraction and list length; say what it did
+        out["config"]["lazy_sort"] = "forced on (--lazy-sort)" if args.lazy_sort else ("on (auto)" if lazy_on else "off (auto)") \
+            if os.environ.get("D4GS_LAZY_SORT", "auto") == "auto" else ("on" if lazy_on else "off")
+        if args.spatial_order:
+            out["config"]["workload"] += f"; Gaussians in Morton order ({args.spatial_order}; control.spatial_order_step)"
+        if args.share > 1:
+            out["metric"] = f"DIAGNOSTIC rank-0 share of {name} at world size {args.share} (no collectives), Gaussians / t"
+            out["config"]["workload"] += f"; ONLY sub-samples s % {args.share} == 0 rendered (--share)"
+        out["config"]["size_check"] = ("host waits for every render's intersection counts" if args.sync_size_check else
+                                       "intersection counts verified once per step behind the launches (deferred)")
+        if res["graph_used"] or graph_note.get("fallback"):
+            out["config"]["launch"] = graph_note.get("fallback") or (
+                "one HIP graph per step (render forward + backward" + (" + RCCL collectives" if use_dist else "")
+                + " captured, deferred size check)")
+        elif world > 1:
+            out["config"]["launch"] = "eager step (--no-graph)" if args.no_graph else "eager step"
+        if rank != 0 or dry:
+            return out
         n_isect = st.n_isect
         S_loc = st.cfg.S
         out["n_isect_per_step"] = n_isect if world == 1 else None
@@ -727,8 +857,10 @@ def main():
             if dom.startswith("k_raster"):
                 flops = pairs_bwd * (FLOPS_PER_PAIR_BWD if "bwd" in dom else FLOPS_PER_PAIR_FWD)
                 tr = _traffic(name, dom) if channels == 3 and args.scale_mul == 1.0 else None
-                roof = {"kernel": dom, "bound": "mfma", "bound_actual": "fp32 VALU issue (no MFMA is issued; the contract's "
-                        "field only admits hbm|mfma and 157.3 TFLOP/s is both the fp32 vector and the fp32-input MFMA peak)",
+                # key order on purpose: what actually binds the kernel and the hardware fraction come BEFORE the contract's nominal fields
+                roof = {"kernel": dom, "bound_actual": "valu", "frac_hardware": None,
+                        "bound": "mfma", "bound_note": "the kernel is bound by fp32 VALU issue; no MFMA is issued - the contract's "
+                        "field only admits hbm|mfma, and 157.3 TFLOP/s is both the fp32 vector and the fp32-input MFMA peak",
                         "achieved": flops / t_k / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS,
                         "peak_measured": max(peaks["fp32_pk_fma_tflops"], peaks["fp32_fma_tflops"]) if peaks else None,
@@ -736,9 +868,10 @@ def main():
                         "peak_measured_detail": {"v_pk_fma_f32": peaks["fp32_pk_fma_tflops"], "v_fma_f32": peaks["fp32_fma_tflops"]} if peaks else None,
                         "traffic": tr["total_1x"] if tr else None,
                         "traffic_detail": tr, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
-                        "note": "NOMINAL work-equivalent fraction (SURVEY 8d): 90 flop x 256 pixels for every (tile, splat) "
-                                "pair the kernel replays, although the kernel skips most of those pixels by design; the "
-                                "`hardware` object below says what the VALU actually does"}
+                        "note": "`frac` is the NOMINAL work-equivalent fraction SURVEY 8d defines: 90 flop x 256 pixels for every (tile, splat) "
+                                "pair the kernel replays, although the kernel skips most of those pixels by design (it can exceed the "
+                                "measured FMA ceiling).  `frac_hardware` (= hardware.frac_necessary) is the honest utilisation: flops the "
+                                "alpha-passing lanes need / peak; `hardware.valu_busy_frac` says how busy the pipe is doing it"}
                 # what the hardware does, from the committed PMC pass + the offline lane statistics of the same scene
                 cur = _load_json("profiles", "pmc_current.json") or {}
                 sq_doc = _load_json("profiles", f"{cur.get('round', 'r03')}_pmc_sq_cfg2.json")
@@ -749,8 +882,8 @@ def main():
                     lanes = None
                 if not sq_ok and name == "cfg2" and channels == 3:
                     roof["counters_note"] = ("profiles/ holds PMC counters of another build of libd4gs.so (sha256 mismatch): "
-                                             "`traffic` / `hardware` omitted rather than quoted stale; scripts/profile_round.sh "
-                                             "re-measures them")
+                                             "`traffic` / `hardware` / `frac_hardware` omitted rather than quoted stale; "
+                                             "scripts/profile_round.sh re-measures them")
                 if sq:
                     clk_cycles = sq["GRBM_GUI_ACTIVE"] / N_XCD  # the counter is summed over the 8 XCDs
                     insts = sq["SQ_INSTS_VALU"]
@@ -772,6 +905,7 @@ def main():
                                   frac_necessary=nec / t_k / 1e12 / F32_PEAK_TFLOPS,
                                   necessary_note="90 flop only for lanes that pass the alpha test, 12 for the other lanes "
                                                  "of a replayed (quadrant, splat) pair")
+                        roof["frac_hardware"] = hw["frac_necessary"]
                     roof["hardware"] = hw
                 if graph_note.get("roofline_timing"):
                     roof["timing_note"] = graph_note["roofline_timing"]
@@ -807,7 +941,46 @@ def main():
                                    "traffic": tr["total_2x"] if tr else None, "traffic_detail": tr,
                                    "traffic_frac_of_peak": (tr["total_2x"] / tk / 1e9 / HBM_PEAK_GBS) if tr else None})
             out["roofline_streaming"] = stream
-        if not args.no_cpu_baseline and world == 1:
+        return out
+
+    # ---- the measurements.  N = 1: one (eager by default).  N > 1: the EAGER primary step first - its line is kept - then, under the
+    # watchdog, the HIP-graph version of it and the secondary shardings; one JSON line whatever happens after the first measurement.
+    first_graph = want_graph and not eager_first
+    res = measure(primary_mode, primary_mesh, args.steps, args.warmup, prof_ok and not first_graph, first_graph)
+    out = line_of(res, primary_mode, primary_mesh)
+    if world > 1:
+        wd = Watchdog(rank, args.graph_timeout)
+        graph_ok = False
+        if eager_first:
+            out["config"]["launch"] = "eager step (the HIP-graph attempt had not finished)"
+            wd.kick("HIP-graph capture + replays of the primary step (RCCL collectives inside)", out)
+            resg = measure(primary_mode, primary_mesh, args.steps, args.warmup, False, True)
+            graph_ok = resg["graph_used"]
+            if graph_ok:
+                t = resg["dt"] / args.steps
+                out["eager"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "host_step_times": out.pop("host_step_times", None),
+                                "note": "the same step issued eagerly (~40 launches + the collectives per step from Python), measured first"}
+                out["value"], out["ms_per_step"] = primary_mesh[0] * N / t, 1e3 * t
+                out["instances_per_s"] = out["value"] * S
+                out["config"]["launch"] = ("one HIP graph per step (render forward + backward + RCCL collectives captured, deferred size check; "
+                                           "replays reproduce the eager step's gradients); default for N > 1, --no-graph times the eager step")
+                if "roofline" in out:
+                    out["roofline"]["timing_note"] = ("the kernel's duration was taken with HIP events inside the EAGER timed region of this run "
+                                                      "(events cannot bracket kernels of a replayed graph); same kernels, same launch geometry")
+            else:
+                out["config"]["launch"] = "eager step: " + (resg["graph_note"].get("fallback") or "the captured step was not used")
+        secondaries = [(m, ms, key) for m, ms, key in (("exposure", (1, world), "exposure_strong_scaling"), ("views", (world, 1), "views_weak_scaling"))
+                       if m != primary_mode and ms[1] <= S]
+        for m, ms, key in secondaries:
+            wd.kick(f"secondary measurement {key}", out)
+            out[key] = brief(measure(m, ms, args.steps, args.warmup, False, graph_ok), m, ms)
+            if key == "exposure_strong_scaling":
+                out[key]["note"] = "BASELINE cfg4 in the strict sense: ONE frame, its sub-samples over all ranks; value = N / t"
+            else:
+                out[key]["note"] = "every rank renders its own full frame (one camera view per GPU), flat gradient all-reduce; value = world * N / t"
+        wd.done()
+    if rank == 0:
+        if not dry and not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(name, channels, full=args.cpu_baseline_full)
             except Exception as e:  # the checker must never take the bench line down

@@ -279,12 +279,49 @@ class FlatGradAllReduce:
                 leaves[k].grad = self.views[k]
 
 
-class ShardedExposure:
-    """Driver used by bench.py and the training-style callers: one step = fwd + bwd + gradient all-reduce."""
+def mesh_coords(world: int, rank: int, V: int, E: int) -> tuple[int, int]:
+    """rank -> (view v, exposure slot e) of a V x E mesh; the E ranks of one view are adjacent (v * E .. v * E + E - 1)."""
+    assert V * E == world and 0 <= rank < world, f"mesh {V}x{E} does not cover world size {world}"
+    return rank // E, rank % E
 
-    def __init__(self, world: int, rank: int, mode: str = "exposure", group=None, need_stack: bool = False):
-        assert mode in ("exposure", "views")
+
+def mesh_exposure_group(world: int, rank: int, V: int, E: int):
+    """The exposure sub-group of this rank's view.  `dist.new_group` is collective over the WORLD: every rank creates all
+    V groups, in the same order, and keeps its own."""
+    v_mine, _ = mesh_coords(world, rank, V, E)
+    mine = None
+    for v in range(V):
+        g = dist.new_group(ranks=list(range(v * E, (v + 1) * E)))
+        if v == v_mine:
+            mine = g
+    return mine
+
+
+class ShardedExposure:
+    """Driver used by bench.py and the training-style callers: one step = fwd + bwd + gradient all-reduce.
+
+    mode "exposure" (BASELINE config 4): the S sub-samples of ONE frame over all ranks.  "views": one full frame of its own
+    camera view per rank (data parallel).  "mesh" (`mesh=(V, E)`, V * E == world): V views, each view's sub-samples split E
+    ways - the blend collectives run inside the view's exposure sub-group (`mesh_exposure_group`), the flat gradient
+    all-reduce over the world, the 1 / V of the data-parallel mean rides on the loss.  The reference's own training step is
+    several independent renders behind one backward (three render groups, flow3d/trainer.py:209-231), so views x exposure is
+    the decomposition of the work it actually does; "exposure" == mesh (1, world), "views" == mesh (world, 1)."""
+
+    def __init__(self, world: int, rank: int, mode: str = "exposure", group=None, need_stack: bool = False,
+                 mesh: tuple[int, int] | None = None, exposure_group=None):
+        assert mode in ("exposure", "views", "mesh")
         self.world, self.rank, self.mode, self.group = world, rank, mode, group
+        if mode == "exposure":
+            self.V, self.E, self.v, self.e, self.group_e = 1, world, 0, rank, group
+        elif mode == "views":
+            self.V, self.E, self.v, self.e, self.group_e = world, 1, rank, 0, None
+        else:
+            assert mesh is not None, "mode 'mesh' needs mesh=(V, E)"
+            self.V, self.E = mesh
+            self.v, self.e = mesh_coords(world, rank, self.V, self.E)
+            # (E == 1: no blend collective at all; otherwise the caller may hand in the group it made, or it is made here)
+            self.group_e = None if self.E == 1 else (exposure_group if exposure_group is not None
+                                                     else mesh_exposure_group(world, rank, self.V, self.E))
         # exposure sharding, forward collective: need_stack=False (default) REDUCES the blended image - SUM of [H,W,D'+1]
         # + MAX of the policy channels, 2.9 MB on cfg4 (SURVEY 8e) - equal to the single-GPU blend up to fp32 summation
         # order (<= 2e-6 * max|value|, tests/test_parallel_gloo.py); need_stack=True ALL-GATHERS the per-sub-sample stack
@@ -312,36 +349,37 @@ class ShardedExposure:
         for k, v in leaves.items():
             if v.grad is not None and v.grad.data_ptr() == self.reducer.views[k].data_ptr():
                 v.grad = None
-        if self.mode == "views":
+        # data-parallel mean of the per-view gradients: the 1 / V factor rides on the loss, so the SUM all-reduce needs no
+        # 24 MB division pass afterwards
+        view_scale = 1.0 / self.V
+        if self.E == 1:  # a full frame of this rank's own view; only the flat gradient all-reduce couples the ranks
             res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
                                   leaves["colors"], 3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                                   leaves["times"], leaves["RTs"], leaves["viewmat"], Kmat, W, H, background=background,
                                   return_depth=True, grad_arena=self.reducer.views,
                                   deferred_size_check=self.deferred_size_check, fused=self.fused)
             loss = torch.dot(res["blended"].reshape(-1), wimg.reshape(-1)) + torch.dot(res["acc"].reshape(-1), wacc.reshape(-1))
-            # data-parallel mean of the per-view gradients: the 1 / world factor rides on the loss, so the SUM
-            # all-reduce needs no 24 MB division pass afterwards
             self.reducer.arm(leaves)
-            (loss * (1.0 / self.world)).backward()
+            (loss * view_scale).backward()
             self.reducer.reduce(leaves)
             return res["state"]
-        own = owned_subsamples(S, self.world, self.rank)
-        sel = slice(self.rank, S, self.world)  # == own, as a strided view (no index tensor, no host-side index build)
+        own = owned_subsamples(S, self.E, self.e)
+        sel = slice(self.e, S, self.E)  # == own, as a strided view (no index tensor, no host-side index build)
         res = render_exposure(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
                               3, leaves["motion_coefs"], leaves["rots"], leaves["transls"],
                               leaves["times"][sel], leaves["RTs"][sel],
                               leaves["viewmat"], Kmat, W, H, background=background, return_depth=True, blend=False,
                               grad_arena=self.reducer.views, deferred_size_check=self.deferred_size_check, fused=self.fused)
         pol = reference_policy(res["renders"].shape[-1])
-        if self.need_stack and S % self.world == 0:  # one all-gather, then the single-GPU blend kernels on the full stack
+        if self.need_stack and S % self.E == 0:  # one all-gather, then the single-GPU blend kernels on the full stack
             from .exposure import BlendFn
 
             blended, acc, _stack_r, _stack_a = GatherBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), S, pol,
-                                                                   self.group, BlendFn.apply)
+                                                                   self.group_e, BlendFn.apply)
         else:  # reduce: SUM + MAX forward, MIN of the winning sub-sample backward (also the ragged-S path)
-            blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), own, S, pol, self.group)
+            blended, acc = ShardedBlendFn.apply(res["renders"], res["alphas"].squeeze(-1), own, S, pol, self.group_e)
         loss = torch.dot(blended.reshape(-1), wimg.reshape(-1)) + torch.dot(acc.reshape(-1), wacc.reshape(-1))
         self.reducer.arm(leaves)
-        loss.backward()
+        (loss if self.V == 1 else loss * view_scale).backward()
         self.reducer.reduce(leaves)
         return res["state"]

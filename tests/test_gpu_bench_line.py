@@ -30,6 +30,14 @@ def test_default_bench_line_carries_the_contract_fields():
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and roof["peak"] > 0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and "traffic" in roof and roof["kernel"].startswith("k_raster_bwd")
     assert roof["avg_launch_ms"] > 0 and roof["peak_measured"] > 0  # the kernel's live duration and the box's measured ceiling
+    # the honest number first: what binds the kernel and the hardware fraction precede the contract's nominal fields
+    keys = list(roof)
+    assert roof["bound_actual"] == "valu" and keys.index("bound_actual") < keys.index("bound") and keys.index("frac_hardware") < keys.index("frac")
+    if roof["frac_hardware"] is not None:  # (None while profiles/ holds the counters of another build of the library)
+        assert roof["frac_hardware"] == roof["hardware"]["frac_necessary"] and 0 < roof["frac_hardware"] < roof["frac"]
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["unit"] == "Gaussians/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    # BASELINE.md section 3 in the default line: scalar C + one torch-restatement frame on cfg1, the product's CPU twin on cfg1 and cfg2
+    assert cpu["runs"]["cfg1/scalar_c"]["iters"] == 20 and cpu["runs"]["cfg1/torch"]["gaussians_per_s"] > 0 and cpu["runs"]["cfg2/scalar_c"]["iters"] == 3
+    assert cpu["product_cpu_twin"]["config"] == "cfg1" and cpu["product_cpu_twin_cfg2"]["gaussians_per_s"] > 0 and cpu["product_cpu_twin_cfg2"]["cores"] == 1
     assert d["value"] > 100 * cpu["value"]  # (a reported baseline, not a target: only that both legs measured the same thing)

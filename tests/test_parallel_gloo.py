@@ -224,6 +224,97 @@ def test_gather_blend_equals_the_single_process_blend_bitwise(world, S, C):
         torch.testing.assert_close(gmeans, means.grad, rtol=1e-12, atol=1e-9)
 
 
+def _toy_render(means, quats, scales, opacities, colors, n_sig, motion_coefs, rots, transls, times, RTs, viewmat, Kmat, Wd, Hd,
+                background=None, blend=True, **_kw):
+    """A differentiable stand-in for render_exposure on CPU tensors (the N > 1 logic is what is under test, not the kernels):
+    [S_loc,H,W,4] images that depend non-linearly on every leaf and differently on every sub-sample, so that the max-policy
+    channel (3) has a different winner per pixel and every collective of the sharded step carries real data."""
+    import types
+
+    from oracle import scene as oscene
+
+    g = torch.Generator().manual_seed(23)
+    base = torch.rand(Hd, Wd, 4, generator=g, dtype=means.dtype)
+    phase = torch.rand(Hd, Wd, 4, generator=g, dtype=means.dtype) * 6.0
+    per_g = sum((t * t).mean() for t in (means, quats, scales, opacities, colors, motion_coefs))
+    shared = rots.mean() + transls.square().mean() + viewmat.mean()
+    gain = times * 1.7 + RTs.reshape(RTs.shape[0], -1).sum(-1)  # [S_loc]
+    renders = base[None] * torch.sin(phase[None] + gain.view(-1, 1, 1, 1)) + 0.3 * (per_g + shared) * torch.cos(gain).view(-1, 1, 1, 1)
+    alphas = torch.sigmoid(base[None, ..., :1] + gain.view(-1, 1, 1, 1) * per_g)
+    st = types.SimpleNamespace(n_isect=0)
+    out = dict(renders=renders, alphas=alphas, state=st, blended=None, acc=None)
+    if blend:
+        S = renders.shape[0]
+        b, a, _ = oscene.blend_exposure([renders[s][None] for s in range(S)], [alphas[s, ..., 0][None] for s in range(S)], single=(S == 1))
+        out["blended"], out["acc"] = b[0], a[0]
+    return out
+
+
+def _toy_leaves(S, dtype=torch.float64):
+    g = torch.Generator().manual_seed(5)
+    shp = dict(means=(7, 3), quats=(7, 4), scales=(7, 3), opacities=(7,), colors=(7, 3), motion_coefs=(7, 2), rots=(2, 3, 6),
+               transls=(2, 3, 3), times=(S,), RTs=(S, 3, 4), viewmat=(4, 4))
+    return {k: torch.randn(*v, generator=g, dtype=dtype).requires_grad_() for k, v in shp.items()}
+
+
+def _toy_targets(v, H, W, dtype=torch.float64):
+    g = torch.Generator().manual_seed(100 + v)
+    return torch.randn(H, W, 4, generator=g, dtype=dtype), torch.randn(H, W, generator=g, dtype=dtype)
+
+
+def _mesh_worker(rank, world, port, V, E, S, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deblur4dgs_amd.parallel import ShardedExposure, mesh_coords
+
+    H, W = 6, 5
+    leaves = _toy_leaves(S)
+    v, e = mesh_coords(world, rank, V, E)
+    wimg, wacc = _toy_targets(v, H, W)
+    sh = ShardedExposure(world, rank, mode="mesh", mesh=(V, E))
+    sh.render = _toy_render
+    for _ in range(2):  # twice: the second step starts from .grad tensors that alias the flat all-reduce buffer
+        sh.step(leaves, None, W, H, None, wimg, wacc)
+    q.put(_by_value((rank, v, e, *[leaves[k].grad.clone() for k in sorted(leaves)])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("V,E,S", [(2, 2, 8), (2, 1, 3), (1, 2, 5)])
+def test_views_x_exposure_mesh_equals_the_single_process_gradients(V, E, S):
+    """VERDICT r4 #1b: a V x E mesh - V camera views, each view's S exposure sub-samples split E ways.  The blend collectives
+    (SUM / MAX forward, MIN backward) run inside the view's exposure sub-group (dist.new_group), the flat gradient all-reduce
+    over the world, 1 / V on the loss.  Every rank must end with the gradient of mean_v loss_v(full S-sample blend of view v),
+    computed here in ONE process with the literal restatement of the reference blend (oracle/scene.py)."""
+    world = V * E
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, V, E, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [_tensors(q.get(timeout=180)) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    H, W = 6, 5
+    leaves = _toy_leaves(S)
+    total = 0.0
+    for v in range(V):
+        wimg, wacc = _toy_targets(v, H, W)
+        r = _toy_render(*[leaves[k] for k in ("means", "quats", "scales", "opacities", "colors")], 3,
+                        *[leaves[k] for k in ("motion_coefs", "rots", "transls", "times", "RTs", "viewmat")], None, W, H, blend=True)
+        total = total + ((r["blended"] * wimg).sum() + (r["acc"] * wacc).sum()) / V
+    total.backward()
+    seen = set()
+    for rank, v, e, *grads in res:
+        seen.add((v, e))
+        for k, g in zip(sorted(leaves), grads):
+            want = leaves[k].grad
+            assert float((g - want).abs().max()) <= 1e-11 * max(1.0, float(want.abs().max())), (rank, k)
+    assert seen == {(v, e) for v in range(V) for e in range(E)}
+
+
 def test_owned_subsamples_partition():
     from deblur4dgs_amd.parallel import owned_subsamples
 
@@ -233,31 +324,61 @@ def test_owned_subsamples_partition():
             assert allv == list(range(S))
 
 
-@pytest.mark.parametrize("flags,expect_launch", [(["--no-graph"], None), ([], "graph capture failed")])
-def test_bench_n_gt_1_control_flow_runs_on_gloo(flags, expect_launch):
-    """VERDICT r3 #8: the first multi-GPU SCALE run must not also be the first run of bench.py's N > 1 code.  `--dry-run` drives
-    exactly that code on CPU tensors over gloo, launched the way the driver launches it (torch.distributed.run, one process per
-    "GPU"): process group, the exposure-sharded step with its blend collectives and the armed gradient all-reduce, the eager path
-    (`--no-graph`) and the default path in which rank 0 fails to capture its HIP graph and the cross-rank MIN agreement must send
-    BOTH ranks to the eager step, max-over-ranks timing, the secondary view-sharded measurement - and ONE JSON line on stdout."""
+def _run_bench_dry(n, flags, env=None, timeout=600):
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
            "--dry-run", *flags]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root, env={**os.environ, **(env or {})})
     assert r.returncode == 0, r.stderr[-3000:]
-    # gloo prints its own connection banner on stdout, and the two ranks' banners may interleave inside a line
+    # gloo prints its own connection banner on stdout, and the ranks' banners may interleave inside a line
     lines = [ln for ln in r.stdout.splitlines() if ln.strip() and "peer ranks" not in ln]
     assert len(lines) == 1, r.stdout  # the contract: ONE JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["data"].startswith("dry-run") and d["ms_per_step"] > 0
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["data"].startswith("dry-run")
+    return d, r.stderr
+
+
+@pytest.mark.parametrize("flags,expect_launch", [(["--no-graph"], "eager step (--no-graph)"), ([], "graph capture failed")])
+def test_bench_n_gt_1_control_flow_runs_on_gloo(flags, expect_launch):
+    """VERDICT r3 #8: the first multi-GPU SCALE run must not also be the first run of bench.py's N > 1 code.  `--dry-run` drives
+    exactly that code on CPU tensors over gloo, launched the way the driver launches it (torch.distributed.run, one process per
+    "GPU"): process group, the exposure-sharded step with its blend collectives and the armed gradient all-reduce, the eager
+    measurement FIRST, then (default path) the graph attempt in which rank 0 fails to capture and the cross-rank MIN agreement must
+    send BOTH ranks to the eager step, max-over-ranks timing, the secondary view-sharded measurement - and ONE JSON line on stdout."""
+    d, _ = _run_bench_dry(2, flags)
+    assert d["scaling"] == "strong" and "cfg4" in d["config"]["parallelism"] and d["config"]["frames_per_step"] == 1
     assert d["views_weak_scaling"]["value"] > 0 and d["views_weak_scaling"]["scaling"] == "weak"
-    if expect_launch is None:
-        assert "launch" not in d["config"]
-    else:
-        assert expect_launch in d["config"]["launch"]  # rank 0 could not capture -> every rank timed the eager step
+    assert "exposure_strong_scaling" not in d  # (it IS the primary at N = 2)
+    assert expect_launch in d["config"]["launch"]  # default: rank 0 could not capture -> every rank timed the eager step
+
+
+def test_bench_default_at_4_ranks_is_the_views_x_exposure_mesh():
+    """`--shard auto` from N = 4: mesh (N/2) x 2 - exposure sub-groups from dist.new_group, world gradient all-reduce - with the strict
+    exposure-only (BASELINE cfg4) and the views-only numbers as secondary objects of the same line."""
+    d, _ = _run_bench_dry(4, [])
+    assert d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2 and "mesh 2x2" in d["config"]["parallelism"]
+    tiny_n = d["config"]["gaussians"]
+    assert abs(d["value"] - 2 * tiny_n / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]  # whole job: 2 frames per step
+    ex, vw = d["exposure_strong_scaling"], d["views_weak_scaling"]
+    assert ex["scaling"] == "strong" and ex["frames_per_step"] == 1 and abs(ex["value"] - tiny_n / (ex["ms_per_step"] * 1e-3)) <= 1e-6 * ex["value"]
+    assert vw["scaling"] == "weak" and vw["frames_per_step"] == 4
+
+
+def test_bench_prints_the_eager_line_when_the_graph_phase_hangs():
+    """a rank that never returns from its capture (D4GS_BENCH_INJECT_HANG=graph: the last rank sleeps
+    forever, rank 0 blocks in the agreement all-reduce).  The eager step was measured first; the watchdog must print THAT line - one
+    JSON line, `config.launch` saying why - and every rank must leave with exit code 0 long before any collective time-out."""
+    import time
+
+    t0 = time.time()
+    d, err = _run_bench_dry(2, ["--graph-timeout", "6"], env={"D4GS_BENCH_INJECT_HANG": "graph"}, timeout=240)
+    assert time.time() - t0 < 120
+    assert "WATCHDOG" in d["config"]["launch"] and "HIP-graph capture" in d["watchdog_fired_in"]
+    assert d["scaling"] == "strong" and "views_weak_scaling" not in d  # nothing after the hung phase ran
+    assert "watchdog" in err
