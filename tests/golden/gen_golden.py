@@ -12,6 +12,10 @@ CPU-runnable parts of the path are covered:
   F4  SE3_to_se3 / se3_to_SE3                             flow3d/models/utils/spline_utils.py:177-215
   F5  MoveModel.forward with a fixed non-zero state_dict  flow3d/models/move_model.py:112-135
   F6  GaussianParams.densify_params / cull_params / reset_opacities   flow3d/params.py:86-118
+  F7  the checkpoint layout: state_dict() of the reference's OWN SceneModel (fg + bg + motion bases + MoveModel), keys, shapes,
+      dtypes and values, and of a foreground-only one                 flow3d/scene_model.py:14-36,145-160, flow3d/params.py:9-37,121-141
+      (SceneModel imports gsplat / cv2 / roma at module level and calls `.cuda()` on its MoveModel: empty stub modules stand in for
+      the three imports - none is called by __init__ / state_dict / init_from_state_dict - and nn.Module.cuda is a no-op here)
 
 `roma`, `pypose`, `jaxtyping` are absent from the image; they are imported by these modules but never
 called on the code paths exercised here, so empty stub modules stand in for the import statements.
@@ -184,6 +188,44 @@ def main():
             f6[f"c{c}_reset_{k}"] = v.detach().numpy()
     f6["n_cases"] = np.int64(3)
     np.savez_compressed(os.path.join(OUT, "f6_control_params.npz"), **f6)
+    # ---- F7 ------------------------------------------------------------------------------------
+    gs = types.ModuleType("gsplat")
+    gs.rendering = types.ModuleType("gsplat.rendering")
+    gs.rendering.rasterization = None
+    sys.modules.setdefault("gsplat", gs)
+    sys.modules.setdefault("gsplat.rendering", gs.rendering)
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    torch.nn.Module.cuda = lambda self, *a, **k: self  # (this generator only: SceneModel.__init__ does MoveModel(...).cuda())
+    from flow3d.scene_model import SceneModel
+
+    gen = torch.Generator().manual_seed(7)
+    r = lambda *sh: torch.randn(*sh, generator=gen)
+    Gf, Gb, K, T, F = 9, 5, 3, 6, 4
+    fg = GaussianParams(r(Gf, 3), r(Gf, 4), r(Gf, 3), r(Gf, 3), r(Gf), motion_coefs=r(Gf, K), scene_center=r(3), scene_scale=torch.tensor(1.7))
+    bg = GaussianParams(r(Gb, 3), r(Gb, 4), r(Gb, 3), r(Gb, 3), r(Gb), scene_center=r(3), scene_scale=torch.tensor(2.3))
+    mb = MotionBases(r(K, T, 6), r(K, T, 3))
+    Ks, w2cs = r(F, 3, 3), r(F, 4, 4)
+    torch.manual_seed(77)
+    full = SceneModel(Ks, w2cs, fg, mb, bg)
+    with torch.no_grad():
+        for p_ in full.move_model.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    f7 = {}
+    for tag, model in (("full", full), ("fgonly", SceneModel(Ks, w2cs, fg, mb, None))):
+        sd = model.state_dict()
+        f7[tag + "_keys"] = np.array(list(sd.keys()))  # in the reference's order
+        for k, v in sd.items():
+            f7[f"{tag}|{k}"] = v.detach().numpy()
+        # and the reference's own loader accepts it (what `init_from_state_dict` needs from a checkpoint)
+        again = SceneModel.init_from_state_dict({k: v.clone() for k, v in sd.items()})
+        assert again.num_fg_gaussians == Gf and again.num_motion_bases == K and again.num_frames == T
+        assert (again.bg is None) == (tag == "fgonly")
+        # ... with its quirk: the buffers `fg.scene_center` / `fg.scene_scale` / `bg.*` are looked up under `fg.params.*` and never
+        # found, so the loaded model is back at centre 0 / scale 1 (and `bg_scene_scale` at 1): recorded as `<tag>_loaded|<key>`
+        for k, v in again.state_dict().items():
+            if not k.startswith("move_model."):  # (a fresh random MoveModel: its weights come from ckpt["move_model"], trainer.py:126-170)
+                f7[f"{tag}_loaded|{k}"] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "f7_state_dict.npz"), **f7)
     print("wrote fixtures to", OUT)
 
 
