@@ -68,7 +68,12 @@ def render_exposure(
         bg_color = torch.cat([bg_color, torch.zeros(1, dtype=dt, device=dev)])
         ds["mask"] = 1
 
-    def poses(ts):
+    def poses(ts, canonical=False):
+        if canonical and fg is not None:  # t is None (the viewer's canonical checkbox, flow3d/renderer.py:74-78): compute_poses_all(None)
+            # = the undeformed means and the normalised quaternions (scene_model.py:84-85,103-105), background appended (:108-120)
+            ps = [p for p in (fg, bg) if p is not None]
+            return (torch.cat([p["means"] for p in ps], 0)[:, None].expand(-1, ts.shape[-1], -1),
+                    torch.cat([deform.act_quats(p["quats"]) for p in ps], 0)[:, None].expand(-1, ts.shape[-1], -1))
         if fg is None:
             return bg["means"][:, None].expand(-1, ts.shape[-1], -1), deform.act_quats(bg["quats"])[
                 :, None
@@ -91,7 +96,7 @@ def render_exposure(
 
     renders, alphas, infos = [], [], []
     for s in range(times.shape[0]):
-        m, q = poses(times[s : s + 1])
+        m, q = poses(times[s : s + 1], canonical=static_time)  # (static_time: `time if t is not None else None`, scene_model.py:327-343)
         m, q = m[:, 0], q[:, 0]
         m = deform.camera_delta(m, RTs[s])
         rc, ra, info = raster.rasterization(

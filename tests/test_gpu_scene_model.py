@@ -236,13 +236,65 @@ def test_render_from_a_loaded_reference_checkpoint(tmp_path):
     assert loaded.fg.params["means"].grad.abs().sum() > 0 and loaded.move_model.time_params.grad is not None
 
 
-def test_render_view_and_inference_mode():
+def _oracle_view(model, w2c, K, t, W, H, stage, return_mask=False):
+    """The viewer's render (mode "mid") through the oracle; t None = the canonical pose."""
+    dd = lambda x: x.detach().double().cpu().clone()
+    fg = {k: dd(v) for k, v in model.fg.params.items()}
+    bg = {k: dd(v) for k, v in model.bg.params.items()} if model.bg is not None else None
+    bases = {k: dd(v) for k, v in model.motion_bases.params.items()}
+    sd = {k: v.detach().cpu().double() for k, v in model.move_model.state_dict().items()}
+    w2c, K = w2c.double().cpu(), K.double().cpu()
+    RTs, times, _ = ocam.forward_start_end_mid(sd, w2c[:3, :3], w2c[:3, 3:4], 0.0 if t is None else t, 11, stage)
+    return oscene.render_exposure(fg, bg, bases, times[0, 5:6].double(), RTs[5:6].double(), w2c, K, (W, H), bg_color=1.0,
+                                  return_mask=return_mask, single=True, static_time=t is None)
+
+
+@pytest.mark.parametrize("t,stage", [(None, "first"), (None, "second"), (2, "second")])
+def test_canonical_pose_render_matches_the_oracle(t, stage):
+    """`render(t=None, ...)`: the undeformed foreground (raw means, normalised quaternions: scene_model.py:84-85,103-105 through
+    `time if t is not None else None`, :327-343) + background, camera delta of the mid sub-sample - by VALUE against the oracle.
+    (Upstream, t=None only survives stage "first": stage "second" evaluates `int(None)`, move_model.py:126; the product reads the
+    MoveModel at timestep 0 there, whose exposure half-width is 0 by the index rule, and renders the same canonical image.)"""
+    dev = torch.device("cuda:0")
+    N, G, K, W, H = 900, 500, 4, 64, 48
+    model, sc = _build(N, G, K, W, H, 23, dev)
+    with torch.no_grad():
+        out = model.render(t, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H), return_mask=True, stage=stage)
+    ref = _oracle_view(model, sc["viewmat"], sc["K"], t, W, H, stage, return_mask=True)
+    case = f"S2 render t={t} stage={stage}"
+    for k in ("img", "mask", "acc"):
+        check(case, k, out[k].cpu(), ref[k], 1e-4, GRAD_FLIP_FRAC)
+    if t is None:  # the canonical image differs from every deformed frame (the test would not notice a swallowed `t is None` otherwise)
+        with torch.no_grad():
+            moved = model.render(2, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (W, H), stage="second")
+        assert rel_err(moved["img"].cpu(), ref["img"]) > 1e-2
+
+
+def test_render_view_values_and_inference_mode():
+    """`Renderer.render_fn`'s arithmetic (flow3d/renderer.py:57-89) by value: K from the vertical fov, w2c = inv(c2w), the mid
+    sub-sample's image as uint8 - for a frame index and for the viewer's canonical checkbox (t = None) - against the oracle driven
+    with the same K / w2c; plus the inference-mode variants (shape contract)."""
+    import math
+
     from deblur4dgs_amd.scene_model import render_view
+    from oracle.camera import se3_to_SE3
 
     dev = torch.device("cuda:0")
-    model, sc = _build(600, 300, 3, 80, 48, 5, dev)
-    img = render_view(model, 2, torch.eye(4, device=dev), 1.2, (80, 48))
-    assert img.shape == (48, 80, 3) and img.dtype == torch.uint8
+    W, H, fov = 80, 48, 1.2
+    model, sc = _build(600, 300, 3, W, H, 5, dev)
+    g = torch.Generator().manual_seed(3)
+    w2c = torch.cat([se3_to_SE3(0.03 * torch.randn(1, 6, generator=g))[0], torch.tensor([[0, 0, 0, 1.0]])], 0)
+    c2w = torch.linalg.inv(w2c)
+    focal = 0.5 * H / math.tan(0.5 * fov)
+    K = torch.tensor([[focal, 0.0, W / 2.0], [0.0, focal, H / 2.0], [0.0, 0.0, 1.0]])
+    for t in (2, None):
+        img = render_view(model, t, c2w.to(dev), fov, (W, H))
+        assert img.shape == (H, W, 3) and img.dtype == torch.uint8
+        ref = _oracle_view(model, torch.linalg.inv(c2w.float()), K, t, W, H, "second")["img"][0]
+        ref8 = (ref * 255.0).to(torch.uint8)  # truncation, as `.astype(np.uint8)` upstream
+        diff = (img.cpu().int() - ref8.int()).abs()
+        assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.02, (t, int(diff.max()), float((diff > 0).float().mean()))
+        assert float(ref8.float().std()) > 10  # (a real image, not a constant background)
     with torch.no_grad():
         o = model.render(2, sc["viewmat"][None].to(dev), sc["K"][None].to(dev), (80, 48), bg_only=True)
         assert o["img"].shape == (1, 48, 80, 3)
