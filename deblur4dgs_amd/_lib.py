@@ -30,7 +30,7 @@ class ProjIn(C.Structure):
 
 class ProjOut(C.Structure):
     _fields_ = [(n, F) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects", "tiles_touched",
-                                 "isect_offsets", "lazy_ws", "tile_counts", "tile_offsets", "n_isect", "scan_ws")]
+                                 "isect_offsets", "lazy_ws", "tile_counts", "tile_offsets", "n_isect", "scan_ws", "blend_bases")]
 
 
 class Isect(C.Structure):
@@ -53,7 +53,7 @@ class Sizes(C.Structure):
                                          "tiles_touched", "isect_offsets", "tile_counts", "tile_offsets", "n_isect",
                                          "scan_ws", "render_colors", "render_alphas", "last_ids", "final_T",
                                          "isect_grad_row", "bwd_partials", "seg_state", "lazy_ws")] + \
-               [(n, C.c_int32) for n in ("tiles_x", "tiles_y", "channels")]
+               [(n, C.c_int32) for n in ("tiles_x", "tiles_y", "channels")] + [("blend_bases", C.c_int64)]
 
 
 class MoveModelParams(C.Structure):
@@ -80,7 +80,7 @@ class ShardBlend(C.Structure):
 
 class FrameIO(C.Structure):
     _fields_ = [(n, F) for n in ("blended", "acc", "renders", "alphas", "means2d", "radii", "n_isect", "background")] + \
-               [("policy", C.POINTER(C.c_int32)), ("near_target", C.c_int64)]
+               [("policy", C.POINTER(C.c_int32)), ("near_target", C.c_int64), ("counts_pinned", F)]
 
 
 class FrameGrads(C.Structure):
@@ -97,7 +97,7 @@ RAW_PARAMS, RAW_COLORS, EXACT_CULL, LAZY_SORT = 1, 2, 4, 8
 DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
 ROWS_AUTO, ROWS_DENSE, ROWS_SPARSE = 0, 1, 2
 TILE = 16
-VERSION = 304  # D4GS_VERSION of include/d4gs.h
+VERSION = 305  # D4GS_VERSION of include/d4gs.h
 GEOM_STRIDE = 8
 
 EXPORTS = (

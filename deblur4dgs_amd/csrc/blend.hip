@@ -19,8 +19,12 @@ struct Policy {
 // (-1: the mean) - the one-call backward reads it instead of re-deriving it from the S - 1 renders (frame.hip, BlendAdj)
 template <bool WIN>
 __global__ void __launch_bounds__(256) k_blend_fwd(int S, int64_t P, int C, const Policy policy, const float *renders,
-                                                   const float *alphas, float *out, float *acc, int8_t *win) {
+                                                   const float *alphas, float *out, float *acc, int8_t *win,
+                                                   const int64_t *__restrict__ n_isect, int64_t *__restrict__ counts_pinned) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // D4gsFrameIO.counts_pinned: the frame's last kernel also reports the list sizes to pinned host memory (every earlier kernel
+  // of the stream - the composite that accumulates n_isect[2..3] included - has completed): k_copy_counts' store, minus its launch
+  if (counts_pinned && i < 4) __hip_atomic_store(counts_pinned + i, n_isect[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int64_t PC = P * C;
   if (i < PC) {
     const int c = (int)(i % C);
@@ -194,8 +198,10 @@ __global__ void __launch_bounds__(256) k_shard_bwd(const ShardArgs a, const floa
 }  // namespace
 
 int d4gs_blend_fwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, const float *renders,
-                        const float *alphas, float *out, float *acc, int8_t *win, hipStream_t stream) {
+                        const float *alphas, float *out, float *acc, int8_t *win, hipStream_t stream,
+                        const int64_t *n_isect, int64_t *counts_pinned) {
   const int64_t n = P * C;
+  if (!n_isect) counts_pinned = nullptr;
   Policy pol;
   if (C > 64 || C <= 0) {
     d4gs_set_error("blend: C=%d out of range (1..64)", C);
@@ -203,9 +209,9 @@ int d4gs_blend_fwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, 
   }
   for (int c = 0; c < 64; c++) pol.p[c] = (c < C && policy) ? (int8_t)policy[c] : 0;
   if (win)
-    D4GS_LAUNCH("k_blend_fwd", k_blend_fwd<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders, alphas, out, acc, win);
+    D4GS_LAUNCH("k_blend_fwd", k_blend_fwd<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders, alphas, out, acc, win, n_isect, counts_pinned);
   else
-    D4GS_LAUNCH("k_blend_fwd", k_blend_fwd<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders, alphas, out, acc, win);
+    D4GS_LAUNCH("k_blend_fwd", k_blend_fwd<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders, alphas, out, acc, win, n_isect, counts_pinned);
   return d4gs_check_launch("k_blend_fwd");
 }
 

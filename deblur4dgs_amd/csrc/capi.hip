@@ -21,7 +21,7 @@ int d4gs_control_stats_impl(int32_t, int32_t, const float *, const int32_t *, in
 int d4gs_control_plan_impl(int32_t, const uint8_t *, const uint8_t *, int32_t *, int32_t *, hipStream_t);
 int d4gs_gather_rows_impl(const int32_t *, int64_t, int32_t, const float *, float *, int64_t, int64_t, float, hipStream_t);
 int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *, int8_t *,
-                        hipStream_t);
+                        hipStream_t, const int64_t *n_isect = nullptr, int64_t *counts_pinned = nullptr);
 int d4gs_blend_bwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
                         const float *, float *, float *, hipStream_t);
 
@@ -123,23 +123,35 @@ int d4gs_version(void) { return D4GS_VERSION; }
 __global__ void k_copy_counts(const int64_t *__restrict__ n_isect, int64_t *__restrict__ host_pinned) {
   if (threadIdx.x < 4) __hip_atomic_store(host_pinned + threadIdx.x, n_isect[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-int d4gs_copy_counts(const int64_t *n_isect, int64_t *host_pinned, void *stream) {
+}  // extern "C"
+int d4gs_copy_counts_impl(const int64_t *n_isect, int64_t *host_pinned, hipStream_t stream) {
   if (!n_isect || !host_pinned) {
     d4gs_set_error("d4gs_copy_counts: NULL argument");
     return D4GS_EINVAL;
   }
   hipPointerAttribute_t at{};
   if (hipPointerGetAttributes(&at, host_pinned) != hipSuccess || at.type != hipMemoryTypeHost) {
-    (void)hipGetLastError();  // pageable memory: the device cannot address it - an ordinary (for pageable memory: synchronous) copy
-    hipError_t e = hipMemcpyAsync(host_pinned, n_isect, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    (void)hipGetLastError();  // pageable memory: the device cannot address it - an ordinary (for pageable memory: synchronous) copy,
+    // which has no place in a stream capture (it would wait for a stream that is only being recorded)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      d4gs_set_error("d4gs_copy_counts: the stream is being captured and the destination is not pinned host memory");
+      return D4GS_EINVAL;
+    }
+    (void)hipGetLastError();
+    hipError_t e = hipMemcpyAsync(host_pinned, n_isect, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) {
       d4gs_set_error("d4gs_copy_counts: %s", hipGetErrorString(e));
       return D4GS_ELAUNCH;
     }
     return D4GS_OK;
   }
-  D4GS_LAUNCH("k_copy_counts", k_copy_counts, dim3(1), dim3(64), 0, (hipStream_t)stream, n_isect, host_pinned);
+  D4GS_LAUNCH("k_copy_counts", k_copy_counts, dim3(1), dim3(64), 0, stream, n_isect, host_pinned);
   return d4gs_check_launch("k_copy_counts");
+}
+extern "C" {
+int d4gs_copy_counts(const int64_t *n_isect, int64_t *host_pinned, void *stream) {
+  return d4gs_copy_counts_impl(n_isect, host_pinned, (hipStream_t)stream);
 }
 
 int d4gs_query_sizes(const D4gsDims *d, D4gsSizes *z) {
@@ -162,6 +174,7 @@ int d4gs_query_sizes(const D4gsDims *d, D4gsSizes *z) {
   z->seg_state = d4gs_seg_state_elems(d);
   z->lazy_ws = d4gs_lazy_ws_elems((int)S, (int)(tw * th));
   z->tiles_x = (int32_t)tw, z->tiles_y = (int32_t)th, z->channels = (int32_t)nch;
+  z->blend_bases = d->G > 0 ? S * (int64_t)d->K * 16 : 0;
   return D4GS_OK;
 }
 

@@ -370,6 +370,8 @@ struct BlendAdj {
 bool d4gs_lazy_on(const D4gsDims *d, const D4gsProjOut *out);
 int d4gs_lazy_pivot_launch(const D4gsDims *d, const D4gsProjOut *out, int64_t near_target, hipStream_t stream);
 int d4gs_lazy_far_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, hipStream_t stream);
+// [S][K][16] time-blended bases (project_bwd.hip: k_bases_table), for callers of d4gs_project_bwd without D4gsProjOut.blend_bases
+int d4gs_bases_table_launch(const D4gsDims *dims, const D4gsProjIn *in, float *btab, hipStream_t stream);
 // Instances per lane of the 1024-lane blocks of k_count_tiles / k_emit (their chunks must agree): 4 - or 1 when 4 would leave
 // fewer blocks than CUs (one or two sub-samples of a few 100 k Gaussians: S = 1, N = 300 k gave 74 blocks for 256 CUs).
 int d4gs_chunk_per_thread(const D4gsDims *d);

@@ -14,7 +14,8 @@ int d4gs_raster_bwd_impl(const D4gsDims *, const D4gsProjOut *, const D4gsIsect 
 int d4gs_project_bwd_impl(const D4gsDims *, const D4gsProjIn *, const D4gsProjOut *, const float *, const float *,
                           const float *, const float *, const float *, const D4gsLeafGrads *, hipStream_t);
 int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, float *, float *, int8_t *,
-                        hipStream_t);
+                        hipStream_t, const int64_t *n_isect = nullptr, int64_t *counts_pinned = nullptr);
+int d4gs_copy_counts_impl(const int64_t *n_isect, int64_t *host_pinned, hipStream_t stream);
 int d4gs_blend_bwd_add_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
                             const float *, float *, float *, const float *, const float *, hipStream_t);
 
@@ -55,6 +56,7 @@ FrameBufs carve(const D4gsDims *d, int64_t cap, void *ws) {
   b.proj.isect_offsets = c.take<int32_t>(z.isect_offsets), b.proj.tile_counts = c.take<int32_t>(z.tile_counts);
   b.proj.tile_offsets = c.take<int32_t>(z.tile_offsets), b.proj.scan_ws = c.take<int32_t>(z.scan_ws);
   b.proj.lazy_ws = (d->flags & D4GS_LAZY_SORT) ? c.take<int32_t>(z.lazy_ws) : nullptr;
+  b.proj.blend_bases = z.blend_bases > 0 ? c.take<float>(z.blend_bases) : nullptr;
   b.isect.keys = c.take<uint64_t>(m), b.isect.gid_of_emit = c.take<int32_t>(m);
   b.isect.sorted_gid = c.take<int32_t>(m), b.isect.sorted_emit = c.take<int32_t>(m);
   b.raster.last_ids = c.take<int32_t>(z.last_ids), b.raster.final_T = c.take<float>(z.final_T);
@@ -121,16 +123,28 @@ int d4gs_forward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *
   int rc = check_frame("d4gs_forward", dims, in, io, ws, ws_bytes, isect_capacity, /*forward_only=*/true);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
+  if (io->counts_pinned) {  // a kernel stores to it: it must be device-addressable host memory (hipHostMalloc / torch pin_memory)
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, io->counts_pinned) != hipSuccess || at.type != hipMemoryTypeHost) {
+      (void)hipGetLastError();
+      d4gs_set_error("d4gs_forward: io->counts_pinned is not pinned host memory");
+      return D4GS_EINVAL;
+    }
+  }
   FrameBufs b = carve(dims, isect_capacity, ws);
   bind_io(b, io, isect_capacity, max_tile_hint);
   if ((rc = d4gs_project_fwd_impl(dims, in, &b.proj, stream))) return rc;
-  if (isect_capacity < 0) return D4GS_OK;  // COUNT ONLY: io->n_isect (and means2d / radii) are what the caller wanted
+  if (isect_capacity < 0)  // COUNT ONLY: io->n_isect (and means2d / radii) are what the caller wanted
+    return io->counts_pinned ? d4gs_copy_counts_impl(io->n_isect, io->counts_pinned, stream) : D4GS_OK;
   if ((rc = d4gs_bin_sort_impl(dims, &b.proj, &b.isect, stream))) return rc;
   if ((rc = d4gs_raster_fwd_impl(dims, &b.proj, &b.isect, &b.raster, stream))) return rc;
   if (io->blended) {
     const int nch = dims->D + (dims->depth_mode != D4GS_DEPTH_NONE ? 1 : 0);
     rc = d4gs_blend_fwd_impl(dims->S, (int64_t)dims->width * dims->height, nch, io->policy, io->renders, io->alphas, io->blended,
-                             io->acc, dims->D <= 5 ? b.blend_win : nullptr, stream);  // (the map is for the folded adjoint: narrow renders)
+                             io->acc, dims->D <= 5 ? b.blend_win : nullptr, stream,  // (the map is for the folded adjoint: narrow renders)
+                             io->n_isect, io->counts_pinned);
+  } else if (io->counts_pinned) {
+    rc = d4gs_copy_counts_impl(io->n_isect, io->counts_pinned, stream);
   }
   return rc;
 }

@@ -47,6 +47,8 @@ struct BwdArgs {
   const float *v_transforms;  // [S,G,3,4] | [G,S,3,4]
   int g_major;                // 1: the Gaussian-major layouts (the reference's (G,B,...) tensors)
   int persist;                // 1: a fixed grid of blocks walks the 64-Gaussian groups and keeps its shared-gradient sums in LDS
+  const float *btab;          // [S][K][16] time-blended bases of every sub-sample (D4gsProjOut.blend_bases, written by k_project_fwd; or
+                              // k_bases_table here, for callers without it), read with scalar loads
 };
 // slots per sub-group for S sub-samples (the poses adjoint keeps the 4-slot mapping: it is not on the per-frame path)
 template <int MODE>
@@ -78,6 +80,29 @@ __device__ __forceinline__ void rotmat_adj_to_quat(const float *q, const float *
   v_q[3] += 2.f * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
 }
 
+// The blended-bases table (round 5).  The time-blended bases of the S sub-samples are the same numbers for every block, yet every wave
+// used to re-blend its sub-sample's [K][9] slab per pass and read it back from LDS twice (54 + 54 broadcast reads at K = 6: two thirds
+// of the kernel's LDS instructions, the LDS pipe ~56 % busy).  With the table in global memory the reads are SCALAR loads (wave-uniform
+// address, constant address space: s_load_dwordx8 + dword per basis) and the values are SGPR operands of the multiply-adds: no LDS
+// traffic, no transient VGPRs (128 VGPRs + a 24-byte scratch frame -> 122, none).  Row stride 16 floats.  Measured (A/B build, same
+// run): cfg2 119.5 -> 112.5 us, cfg3 118.5 -> 112.6, refdefault (K = 20) 128 -> 118, cfg5 (K = 12) 967 -> 736 (profiles/r05_ab_bases_table.txt).
+__global__ void __launch_bounds__(256) k_bases_table(const D4gsDims d, const float *times, const float *rots, const float *transls, float *btab) {
+  const int s = blockIdx.x, K = d.K, T = d.T;
+  const float t = times[s];
+  const float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));
+  const float cf_ = fminf(fmaxf(ceilf(t), 0.f), (float)(T - 1));
+  const float w = t - ff;
+  const int f = (int)ff, c = (int)cf_;
+  for (int idx = threadIdx.x; idx < K * 16; idx += 256) {
+    const int k = idx >> 4, j = idx & 15;
+    float v = 0.f;
+    if (j < 3) v = (1.f - w) * transls[(k * T + f) * 3 + j] + w * transls[(k * T + c) * 3 + j];
+    else if (j < 9) v = (1.f - w) * rots[(k * T + f) * 6 + j - 3] + w * rots[(k * T + c) * 6 + j - 3];
+    btab[((size_t)s * K + k) * 16 + j] = v;
+  }
+}
+typedef const __attribute__((address_space(4))) float *cfloat_p;
+#define PB_BROW(k_) ((cfloat_p)(uintptr_t)a.btab + ((size_t)s * K + (k_)) * 16)
 template <int MODE, bool MFMA /* K > 8: basis-gradient column sums on the matrix pipe */, int SL /* slots per sub-group */>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ? PB_MFMA_WAVES : 4))) k_project_bwd(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -92,8 +117,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   constexpr int NSG = SLOTS / SL;  // sub-groups per block (SL = 4: one, the round-3 mapping)
   float *cf = smem;                   // [NSG][GPB][KP] softmaxed coefficients of the block's Gaussians
   float *vcf = cf + NSG * GPB * KP;   // [BLK][KP]    their gradients, per slot, summed over the slot's sub-samples
-  float *bsl = vcf + BLK * KP;        // [SLOTS][2][nk4] time-blended bases of the sub-sample each wave is working on / will work on next
-  float *red = bsl + 2 * SLOTS * nk4; // [SLOTS][nop] per-wave reduction slab (+ dump slot)
+  float *red = vcf + BLK * KP;        // [SLOTS][nop] per-wave reduction slab (+ dump slot)
   constexpr int NACC = nacc_of(MFMA);
   float *accs = red + SLOTS * nop;    // [BLK][NACC]  per-lane leaf accumulators (cross-slot sum at the end)
   float *svec = accs + BLK * NACC;    // [BLK][9]     K > 8 only: (v_transl 3, v_r6 6) of every lane, MFMA B operand
@@ -169,52 +193,10 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   float *part = a.persist ? wacc + sub * a.n_shared : a.g.partials + ((size_t)grp * NSG + sub) * a.n_shared;
   float *mine = red + wv * nop;
 
-  // Time-blended bases of sub-sample s (params.py:152-177; w uses the clamped floor): element idx = lane + 64 m of the
-  // wave's [K][9] slab.  The loads for the NEXT sub-sample of this slot are issued at the top of a pass and the slab is
-  // written at its end (two slabs per wave), so their latency hides behind the adjoint chain.
-  constexpr int NBV = MFMA ? (D4GS_MAX_K * 9 + 63) / 64 : 2;  // K <= 8 without the matrix pipe: 72 elements
-  float bvf[NBV], bvc[NBV], bw = 0.f;
-  auto bases_load = [&](int s_) {
-    const int T = d.T;
-    const float t = a.in.times[s_];
-    const float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));
-    const float cfl = fminf(fmaxf(ceilf(t), 0.f), (float)(T - 1));
-    bw = t - ff;
-    const int f = (int)ff, c = (int)cfl;
-#pragma unroll
-    for (int m = 0; m < NBV; m++) {
-      const int idx = lane + 64 * m;
-      bvf[m] = bvc[m] = 0.f;
-      if (idx < nk) {
-        const int k = idx / 9, j = idx - k * 9;
-        if (j < 3) {
-          bvf[m] = a.in.transls[(k * T + f) * 3 + j];
-          bvc[m] = a.in.transls[(k * T + c) * 3 + j];
-        } else {
-          bvf[m] = a.in.rots[(k * T + f) * 6 + j - 3];
-          bvc[m] = a.in.rots[(k * T + c) * 6 + j - 3];
-        }
-      }
-    }
-  };
-  auto bases_store = [&](float *dst) {
-#pragma unroll
-    for (int m = 0; m < NBV; m++) {
-      const int idx = lane + 64 * m;
-      if (idx < nk) dst[idx] = (1.f - bw) * bvf[m] + bw * bvc[m];
-    }
-  };
-  int cur = 0;
-  if (dyn_block && slot < S) {
-    bases_load(slot);
-    bases_store(bsl + (wv * 2) * nk4);
-  }
+  // Time-blended bases of sub-sample s (params.py:152-177; w uses the clamped floor): rows of the global table a.btab, read with
+  // SCALAR loads where they are used (PB_BROW) - rounds 3-4 re-blended a [K][9] LDS slab per wave and pass and read it back twice.
 
-  for (int s = slot; s < S; s += SL, cur ^= 1) {  // wave-uniform
-    const float *B = bsl + (wv * 2 + cur) * nk4;
-    const bool more = dyn_block && s + SL < S;
-    __builtin_amdgcn_wave_barrier();
-    if (more) bases_load(s + SL);
+  for (int s = slot; s < S; s += SL) {  // wave-uniform
     float vec[21];  // v9 adjoint (transl 3 + r6 6) + camera-delta adjoint 12
 #pragma unroll
     for (int r = 0; r < 21; r++) vec[r] = 0.f;
@@ -243,8 +225,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
         for (int j = 0; j < 9; j++) v9[j] = 0.f;
         for (int k = 0; k < K; k++) {
           float c = cfl[k];
+          cfloat_p Bk = PB_BROW(k);
 #pragma unroll
-          for (int j = 0; j < 9; j++) v9[j] += c * B[k * 9 + j];
+          for (int j = 0; j < 9; j++) v9[j] += c * Bk[j];
         }
         GS6 gs;
         gram_schmidt(v9 + 3, gs);
@@ -473,8 +456,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
         // coefficient gradients: v_c[k] += B_s[k] . vec[0:9]
         for (int k = 0; k < K; k++) {
           float acc = 0.f;
+          cfloat_p Bk = PB_BROW(k);
 #pragma unroll
-          for (int j = 0; j < 9; j++) acc += B[k * 9 + j] * vec[j];
+          for (int j = 0; j < 9; j++) acc += Bk[j] * vec[j];
           vcf[tid * KP + k] += acc;
         }
       } else {
@@ -550,7 +534,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (more) bases_store(bsl + (wv * 2 + (cur ^ 1)) * nk4);
   }
 
   // ---- viewmat partials (12 plain column sums): per-wave ladder + fixed-order sum of the 4 slots ----
@@ -676,12 +659,12 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float *partials, 
 // `red_in`: n_in > 0: [n_in][n_shared] chunk sums of k_reduce_partials' first pass - every block first adds them (the second
 // pass's arithmetic and order, so the totals are the same bits) into LDS and works from there: one launch less per frame;
 // n_in == 0: the [n_shared] totals themselves, in global memory (shared vectors beyond the LDS budget).
-__global__ void __launch_bounds__(256) k_finish(const BwdArgs a, const float *red_in, int n_in) {
+__global__ void __launch_bounds__(1024) k_finish(const BwdArgs a, const float *red_in, int n_in) {
   extern __shared__ __attribute__((aligned(16))) float sred[];
   const float *red = red_in;
   if (n_in > 0) {
     const int n = a.n_shared;
-    for (int o = threadIdx.x; o < n; o += 256) {
+    for (int o = threadIdx.x; o < n; o += blockDim.x) {
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       int b = 0;
 #pragma unroll 4
@@ -702,7 +685,10 @@ __global__ void __launch_bounds__(256) k_finish(const BwdArgs a, const float *re
   const bool dyn = d.G > 0;
   const int nk = dyn ? K * 9 : 0;
   const int stride = nk + 12;
-  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  int fin = dyn ? K * T * 9 : 0;
+  fin = max(max(fin, S * 12), 16);
+  // (grid-stride: the mid-size launch is ONE block of 1 024 lanes that has just summed the chunk sums into LDS)
+  for (int gtid = blockIdx.x * blockDim.x + threadIdx.x; gtid < fin; gtid += gridDim.x * blockDim.x) {
   if (dyn) {
     if (gtid < K * T * 9) {
       const int k = gtid / (T * 9), r = gtid - k * T * 9, fr = r / 9, j = r - fr * 9;
@@ -750,11 +736,17 @@ __global__ void __launch_bounds__(256) k_finish(const BwdArgs a, const float *re
     if (r < 3) v = c < 3 ? red[S * stride + r * 3 + c] : red[S * stride + 9 + r];
     a.g.v_viewmat[gtid] = v;
   }
+  }
 }
 
 int n_shared_of(const D4gsDims *d) { return d->S * ((d->G > 0 ? d->K * 9 : 0) + 12) + 12; }
 
 }  // namespace
+
+int d4gs_bases_table_launch(const D4gsDims *dims, const D4gsProjIn *in, float *btab, hipStream_t stream) {
+  D4GS_LAUNCH("k_bases_table", k_bases_table, dim3(dims->S), dim3(256), 0, stream, *dims, in->times, in->rots, in->transls, btab);
+  return d4gs_check_launch("k_bases_table");
+}
 
 constexpr int PERSIST_MAX_SHARED = 8192;  // floats of LDS a block may spend on its shared-gradient sums
 
@@ -809,7 +801,7 @@ static BwdPlan plan_bwd(const D4gsDims *dims) {
   p.fn = kernel_of<MODE>(K > 8, p.sl);
   const int nsg = SLOTS / p.sl;
   auto lds_of = [&](bool persist) {
-    return sizeof(float) * ((size_t)nsg * GPB * KP + (size_t)BLK * KP + 2 * SLOTS * ((nk + 3) & ~(size_t)3) + SLOTS * (nk + 13) +
+    return sizeof(float) * ((size_t)nsg * GPB * KP + (size_t)BLK * KP + SLOTS * (nk + 13) +
                             (size_t)BLK * nacc_of(K > 8) + (K > 8 ? (size_t)BLK * 9 : 0) + (persist ? (size_t)nsg * n_shared : 0));
   };
   p.blocks = (dims->N + nsg * GPB - 1) / (nsg * GPB);
@@ -835,11 +827,13 @@ static BwdPlan plan_bwd(const D4gsDims *dims) {
 extern "C" size_t d4gs_bwd_partials_elems(const D4gsDims *d) {
   // (the render and the poses instantiation have different register counts: take the larger grid of the two)
   const int b0 = plan_bwd<MODE_RENDER>(d).nparts, b1 = plan_bwd<MODE_POSES>(d).nparts;
-  return ((size_t)(b0 > b1 ? b0 : b1) + RCH + 1) * (size_t)n_shared_of(d);
+  const size_t extra = (size_t)d->S * (d->G > 0 ? d->K : 0) * 16;  // room for the blended-bases table of a caller without one
+  return ((size_t)(b0 > b1 ? b0 : b1) + RCH + 1) * (size_t)n_shared_of(d) + extra;
 }
 
 template <int MODE>
-static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGrads *grads, hipStream_t stream) {
+static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGrads *grads, hipStream_t stream,
+                              const float *blend_bases = nullptr) {
   a.n_shared = n_shared_of(dims);
   const BwdPlan pl = plan_bwd<MODE>(dims);
   a.persist = pl.persist;
@@ -852,6 +846,13 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   if (lds > 64 * 1024)  // per call: the attribute belongs to the (function, device) pair and a process may drive several GPUs
     (void)hipFuncSetAttribute(pl.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const char *name = MODE == MODE_RENDER ? "k_project_bwd" : "k_project_bwd[poses]";
+  a.btab = blend_bases;  // D4gsProjOut.blend_bases, left by k_project_fwd
+  if (dims->G > 0 && !blend_bases) {  // a caller without it (and the poses adjoint): built here, behind the partial vectors
+    float *btab = grads->partials + ((size_t)pl.nparts + RCH + 1) * a.n_shared;
+    a.btab = btab;
+    int rc0 = d4gs_bases_table_launch(dims, &a.in, btab, stream);
+    if (rc0) return rc0;
+  }
   {
     ProfScope _ps(name, stream);
     void *kargs[] = {(void *)&a};
@@ -872,6 +873,14 @@ static int launch_project_bwd(BwdArgs &a, const D4gsDims *dims, const D4gsLeafGr
   // (measured: cfg2 S = 8, 540 floats: 13 -> 19 us; refdefault, 2 124 floats: 13 -> 60 us; S = 1, 78 floats: 24 -> 16 us)
   if (a.n_shared <= 160) {
     D4GS_LAUNCH("k_finish", k_finish, dim3((fin + 255) / 256), dim3(256), fin_lds, stream, a, (const float *)red2, RCH);
+    return d4gs_check_launch("k_finish");
+  }
+  // Mid-size shared vectors (round 5; cfg2: 540 floats, 1 296 leaf elements): ONE block of 1 024 lanes does the second pass once - RCH x
+  // n_shared coalesced loads, the same additions in the same order, so the totals are the same bits - and then walks the leaf elements
+  // itself: one launch instead of two (k_reduce_partials' second pass + a six-block k_finish).  D4GS_FINISH_ONE=0: the two launches (A/B).
+  static const bool one_env = []() { const char *e = getenv("D4GS_FINISH_ONE"); return !(e && e[0] == '0'); }();
+  if (one_env && a.n_shared <= 1024 && fin <= 8192) {
+    D4GS_LAUNCH("k_finish", k_finish, dim3(1), dim3(1024), fin_lds, stream, a, (const float *)red2, RCH);
     return d4gs_check_launch("k_finish");
   }
   D4GS_LAUNCH("k_reduce_partials", k_reduce_partials, dim3((a.n_shared + 255) / 256, 1), dim3(256), 0, stream,
@@ -899,5 +908,5 @@ int d4gs_project_bwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   a.radii = proj->radii, a.conics = proj->conics, a.ctab = proj->ctab, a.opac_act = proj->opac_act;
   a.v_means2d = v_means2d, a.v_conics = v_conics, a.v_depths = v_depths, a.v_opac_act = v_opac_act, a.v_ctab = v_ctab;
   a.g = *grads;
-  return launch_project_bwd<MODE_RENDER>(a, dims, grads, stream);
+  return launch_project_bwd<MODE_RENDER>(a, dims, grads, stream, proj->blend_bases);
 }

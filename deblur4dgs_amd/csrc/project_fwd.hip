@@ -64,7 +64,18 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
     const int64_t nl = d4gs_lazy_ws_elems(S, a.tw * a.th);
     for (int64_t z = g; z < nl; z += (int64_t)gridDim.x * D4GS_PROJ_BLOCK) a.out.lazy_ws[z] = 0;
   }
+#ifdef PF_BASES_TABLE  // (A/B) the table was built by a launch in front of this kernel: scalar loads below, no LDS slab
+  typedef const __attribute__((address_space(4))) float *cfloat_p;
+#else
   if (dyn_block) preblend_bases(a, Bs);
+  if (blockIdx.x == 0 && dyn_block && a.out.blend_bases) {  // the table k_project_bwd reads with scalar loads (include/d4gs.h)
+    __syncthreads();
+    for (int idx = tid; idx < S * K * 16; idx += D4GS_PROJ_BLOCK) {
+      const int j = idx & 15, sk = idx >> 4;
+      a.out.blend_bases[idx] = j < 9 ? Bs[sk * 9 + j] : 0.f;
+    }
+  }
+#endif
 
   const bool active = g < N;
   const bool raw = d.flags & D4GS_RAW_PARAMS;
@@ -112,19 +123,28 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
   if (dyn_block) __syncthreads();
 
   // each wave walks the sub-samples from a different start, so resident waves hit all S*tiles counters at once
-  const int rot = (blockIdx.x * (D4GS_PROJ_BLOCK / 64) + (tid >> 6)) % S;
+  const int rot = __builtin_amdgcn_readfirstlane((blockIdx.x * (D4GS_PROJ_BLOCK / 64) + (tid >> 6)) % S);
   for (int it = 0; it < S; it++) {
     if (!active) continue;
     const int s = (it + rot) % S;
     float mw[3], Rm[9];
     if (g < G) {
       float v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef PF_BASES_TABLE
+      for (int k = 0; k < K; k++) {
+        float c = cf[k * D4GS_PROJ_BLOCK + tid];
+        cfloat_p Bk = (cfloat_p)(uintptr_t)a.out.blend_bases + ((size_t)s * K + k) * 16;
+#pragma unroll
+        for (int j = 0; j < 9; j++) v9[j] += c * Bk[j];
+      }
+#else
       const float *B = Bs + s * K * 9;
       for (int k = 0; k < K; k++) {
         float c = cf[k * D4GS_PROJ_BLOCK + tid];
 #pragma unroll
         for (int j = 0; j < 9; j++) v9[j] += c * B[k * 9 + j];
       }
+#endif
       GS6 gs;
       gram_schmidt(v9 + 3, gs);
       float Rd[9] = {gs.x[0], gs.y[0], gs.z[0], gs.x[1], gs.y[1], gs.z[1], gs.x[2], gs.y[2], gs.z[2]};
@@ -610,6 +630,16 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
       return D4GS_ELAUNCH;
     }
   }
+#ifdef PF_BASES_TABLE
+  if (dims->G > 0) {
+    if (!out->blend_bases) {
+      d4gs_set_error("PF_BASES_TABLE build: D4gsProjOut.blend_bases is required");
+      return D4GS_EINVAL;
+    }
+    int rc0 = d4gs_bases_table_launch(dims, in, out->blend_bases, stream);
+    if (rc0) return rc0;
+  }
+#endif
   D4GS_LAUNCH("k_project_fwd", k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
   int rc = d4gs_check_launch("k_project_fwd");
   if (rc) return rc;

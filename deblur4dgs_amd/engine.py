@@ -425,6 +425,7 @@ class ProjectFn(torch.autograd.Function):
             tile_counts=torch.empty(2 * S * tw * th, **i32),
             tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(4, dtype=torch.int64, device=dev),
             scan_ws=torch.empty(lib.d4gs_scan_ws_elems(S * N), **i32),
+            blend_bases=torch.empty(S * cfg.K * 16, **f32) if cfg.G > 0 else None,  # the backward's scalar-load table (include/d4gs.h)
         )
         dims = cfg.dims()
         pin, pout = _proj_structs(st)
@@ -501,12 +502,14 @@ def _check_stats(cs: dict, N: int) -> dict:
     return cs
 
 
-def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch: bool = False):
+def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch: bool = False, fused_counts: bool = False):
     """The intersection-list size protocol shared by the staged and the one-call path.  `launch(capacity, max_tile_hint)`
     allocates the lists and enqueues binning + rasterization (every kernel checks the device-side count against the
     capacity); `n_isect_dev()` is the device int64[4] {count, longest tile list, live-row sample x 2} of the launch just made (staged path:
     already there, the projection ran before; one-call path, `count_needs_launch`: a capacity-0 call whose list kernels
-    all return at once does the counting).  -> (capacity or exact count, max-tile value) the backward must use."""
+    all return at once does the counting).  `fused_counts`: `launch` takes a third argument, the address of a pinned int64[4] its
+    LAST kernel stores the counts to (D4gsFrameIO.counts_pinned: no d4gs_copy_counts launch behind it; 0 = none wanted).
+    -> (capacity or exact count, max-tile value) the backward must use."""
     key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
     if cfg.deferred_size_check:
         capturing = torch.cuda.is_current_stream_capturing()
@@ -516,8 +519,20 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
         if guess is not None:
             # deferred check: launch at the guessed capacity, never wait.  The count travels to pinned memory behind
             # the launches and is looked at by a later call (not under stream capture: a graph replays this shape).
-            launch(*guess)
             watch = _graph_watch()
+            host_n = None
+            if fused_counts:  # the pinned buffer is chosen BEFORE the launch: the frame's last kernel stores the counts there
+                if capturing and watch is not None:
+                    host_n = watch.take()
+                elif not capturing:
+                    with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
+                        host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
+                    if host_n is None:
+                        host_n = torch.empty(4, dtype=torch.int64).pin_memory()
+                launch(*guess, 0 if host_n is None else host_n.data_ptr())
+            else:
+                launch(*guess)
+            stored = host_n is not None
             if capturing and watch is None:
                 global _WARNED_UNWATCHED
                 if not _WARNED_UNWATCHED:
@@ -532,17 +547,19 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
                 # the copy of the counts becomes a node of the graph: every replay leaves them in this record's pinned buffer
                 # (a raw hipMemcpyAsync into memory pinned BEFORE the capture: neither an allocation nor torch's host-allocator
                 # bookkeeping may happen on a capturing stream)
-                host_n = watch.take()
-                L.check(L.lib().d4gs_copy_counts(L.ptr(n_isect_dev()), host_n.data_ptr(), raw_stream(dev.index)), "copy_counts")
+                if not stored:
+                    host_n = watch.take()
+                    L.check(L.lib().d4gs_copy_counts(L.ptr(n_isect_dev()), host_n.data_ptr(), raw_stream(dev.index)), "copy_counts")
                 watch.recs.append((key, host_n, guess[0], guess[1]))
             if not capturing:
-                with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
-                    host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
-                if host_n is None:
-                    host_n = torch.empty(4, dtype=torch.int64).pin_memory()
-                # (a kernel stores the counts into the pinned buffer: a device-to-host copy here is a DMA-engine trip the backward's
-                # kernels would wait for)
-                L.check(L.lib().d4gs_copy_counts(L.ptr(n_isect_dev()), host_n.data_ptr(), raw_stream(dev.index)), "copy_counts")
+                if not stored:
+                    with _SIZE_LOCK:  # pinned pairs are recycled once their count has been read (pin_memory() costs ~0.1 ms)
+                        host_n = _PINNED_FREE.pop() if _PINNED_FREE else None
+                    if host_n is None:
+                        host_n = torch.empty(4, dtype=torch.int64).pin_memory()
+                    # (a kernel stores the counts into the pinned buffer: a device-to-host copy here is a DMA-engine trip the
+                    # backward's kernels would wait for)
+                    L.check(L.lib().d4gs_copy_counts(L.ptr(n_isect_dev()), host_n.data_ptr(), raw_stream(dev.index)), "copy_counts")
                 ev = torch.cuda.Event()
                 ev.record()
                 with _SIZE_LOCK:
@@ -718,16 +735,17 @@ class FrameFn(torch.autograd.Function):
         # scratch - about half of the workspace, pinned by the returned state for as long as the caller keeps it
         ws_bytes_of = lib.d4gs_frame_workspace_bytes if st.want_grad else lib.d4gs_frame_workspace_bytes_fwd
 
-        def launch(cap, max_hint):
+        def launch(cap, max_hint, counts_ptr=0):
             nbytes = ws_bytes_of(C.byref(dims), cap)
             st.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
             st.ws_ptr = (st.ws.data_ptr() + 255) & ~255
             st.ws_bytes = nbytes
             st.ws_cap = (cap, max_hint)  # the workspace layout follows the capacity: the backward must carve it the same way
+            fio.counts_pinned = counts_ptr or None  # (deferred size check: the frame's last kernel reports the list sizes itself)
             L.check(lib.d4gs_forward(C.byref(dims), C.byref(pin), C.byref(fio), C.c_void_p(st.ws_ptr), nbytes, cap, max_hint,
                                      _stream()), "d4gs_forward")
 
-        st.n_isect, st.max_tile = _sized_launch(cfg, dev, lambda: io["n_isect"], launch, count_needs_launch=True)
+        st.n_isect, st.max_tile = _sized_launch(cfg, dev, lambda: io["n_isect"], launch, count_needs_launch=True, fused_counts=True)
         st.binned = True
         st.frame_io, st.policy = io, pol
         ctx.st = st

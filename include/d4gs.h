@@ -31,7 +31,7 @@ extern "C" {
 /* libd4gs.so is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table. */
 #define D4GS_API __attribute__((visibility("default")))
 
-#define D4GS_VERSION 304
+#define D4GS_VERSION 305
 #define D4GS_TILE 16
 #define D4GS_GEOM_STRIDE 8 /* floats per instance record: x, y, opacity, depth, conic a, b, c, pad */
 
@@ -121,6 +121,9 @@ typedef struct D4gsProjOut {
                               contributor, i.e. the rows the backward will replay.  [3] / [2] estimates the live fraction a
                               caller can choose D4gsRasterGrads.row_mode from (deblur4dgs_amd/engine.py does, one render late) */
   int32_t *scan_ws;        /* [d4gs_scan_ws_elems(S*N)] scratch */
+  float *blend_bases;      /* [S,K,16] or NULL (v305, appended): the time-blended motion bases of the S sub-samples (row k: transl 3,
+                              6-D rotation 6, 7 pad floats), written by d4gs_project_fwd when G > 0 and read by d4gs_project_bwd with
+                              scalar loads.  NULL: d4gs_project_bwd builds the table itself (one small launch more). */
 } D4gsProjOut;
 
 typedef struct D4gsIsect {
@@ -231,6 +234,7 @@ typedef struct {
   int64_t seg_state;                                             /* D4gsRaster.seg_state; 0 = this configuration does not use depth segments */
   int64_t lazy_ws;                                               /* D4gsProjOut.lazy_ws (int32 elements; needed with D4GS_LAZY_SORT only) */
   int32_t tiles_x, tiles_y, channels;                            /* tile grid; D + depth channel */
+  int64_t blend_bases;                                           /* D4gsProjOut.blend_bases (v305, appended; 0 when G == 0) */
 } D4gsSizes;
 D4GS_API int d4gs_query_sizes(const D4gsDims *dims, D4gsSizes *sizes);
 
@@ -411,6 +415,10 @@ typedef struct D4gsFrameIO {
   const float *background; /* [D] or NULL */
   const int32_t *policy;   /* [host] [D+depth] blend policy per channel (0 mean, 1 max, 2 min) or NULL = all mean */
   int64_t near_target;     /* [host] D4GS_LAZY_SORT: D4gsIsect.near_target of the frame (<= 0: 1024) */
+  int64_t *counts_pinned;  /* [PINNED host memory, device-addressable] [4] or NULL (v305, appended): d4gs_forward also leaves the four
+                              counts of n_isect there - stored by its LAST kernel (the blend, when io->blended is given: no extra
+                              launch; otherwise one one-wave kernel), i.e. what d4gs_copy_counts would do in a launch of its own.
+                              Read it after an event recorded behind d4gs_forward has completed. */
 } D4gsFrameIO;
 typedef struct D4gsFrameGrads {
   const float *v_blended, *v_acc;     /* [H,W,D+depth], [H,W] or NULL */

@@ -46,7 +46,7 @@ def test_dynamic_symbol_table_is_exactly_the_header(lib):
 def test_version_and_error_paths(lib):
     from deblur4dgs_amd import _lib as L
 
-    assert lib.d4gs_version() == 304
+    assert lib.d4gs_version() == 305
     lib.d4gs_last_error.restype = C.c_char_p
     assert lib.d4gs_project_fwd(None, None, None, None) == -1  # D4GS_EINVAL, no HIP call made
     assert b"NULL" in lib.d4gs_last_error()
