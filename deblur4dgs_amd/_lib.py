@@ -30,7 +30,8 @@ class ProjIn(C.Structure):
 
 class ProjOut(C.Structure):
     _fields_ = [(n, F) for n in ("means2d", "depths", "conics", "radii", "opac_act", "ctab", "geom", "tile_rects", "tiles_touched",
-                                 "isect_offsets", "lazy_ws", "tile_counts", "tile_offsets", "n_isect", "scan_ws", "blend_bases")]
+                                 "isect_offsets", "lazy_ws", "tile_counts", "tile_offsets", "n_isect", "scan_ws", "blend_bases",
+                                 "tile_masks")]
 
 
 class Isect(C.Structure):
@@ -53,7 +54,7 @@ class Sizes(C.Structure):
                                          "tiles_touched", "isect_offsets", "tile_counts", "tile_offsets", "n_isect",
                                          "scan_ws", "render_colors", "render_alphas", "last_ids", "final_T",
                                          "isect_grad_row", "bwd_partials", "seg_state", "lazy_ws")] + \
-               [(n, C.c_int32) for n in ("tiles_x", "tiles_y", "channels")] + [("blend_bases", C.c_int64)]
+               [(n, C.c_int32) for n in ("tiles_x", "tiles_y", "channels")] + [("blend_bases", C.c_int64), ("tile_masks", C.c_int64)]
 
 
 class MoveModelParams(C.Structure):
@@ -93,7 +94,7 @@ class Poses(C.Structure):
     _fields_ = [("means", F), ("quats", F), ("transforms", F), ("g_major", C.c_int32)]
 
 
-RAW_PARAMS, RAW_COLORS, EXACT_CULL, LAZY_SORT = 1, 2, 4, 8
+RAW_PARAMS, RAW_COLORS, EXACT_CULL, LAZY_SORT, EXACT_TILES = 1, 2, 4, 8, 16
 DEPTH_NONE, DEPTH_ED, DEPTH_D = 0, 1, 2
 ROWS_AUTO, ROWS_DENSE, ROWS_SPARSE = 0, 1, 2
 TILE = 16

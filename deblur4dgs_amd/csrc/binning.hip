@@ -31,6 +31,7 @@ struct EmitArgs {
   int64_t cap, max_hint;
   int use_lds;
   LazyWs lazy;  // D4GS_LAZY_SORT instantiation: near / far partition of every list (common.h)
+  const uint64_t *tile_masks;  // D4GS_EXACT_TILES: per instance, the tiles of its rectangle that are binned (0: all of them); or NULL
 };
 
 // D4gsIsect.n_isect is a CAPACITY: the host may size the lists from a guess and look at the real count afterwards.
@@ -88,10 +89,11 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
   }
   auto taken = [&](int bk, int t) -> bool { return LZ == 1 ? bk <= piv[t] : bk > piv[t]; };
   int cnt[EMIT_PER_THREAD], rx[EMIT_PER_THREAD], ry[EMIT_PER_THREAD], bkq[EMIT_PER_THREAD];
+  uint64_t msk[EMIT_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < EMIT_PER_THREAD; q++) {
     const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
-    cnt[q] = 0;
+    cnt[q] = 0, msk[q] = 0;
     if (g < a.d.N) {
       const int64_t i = (int64_t)s * a.d.N + g;
       cnt[q] = a.tiles_touched[i];
@@ -104,7 +106,13 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
           continue;
         }
         bkq[q] = LAZY ? d4gs_depth_bucket(a.depths[i], zlo, zhi, a.lazy.nb) : 0;
-        if (lds) {
+        msk[q] = a.tile_masks ? a.tile_masks[i] : 0;
+        if (lds && msk[q]) {  // D4GS_EXACT_TILES: bit (ty - y0) * 8 + (tx - x0)
+          for (uint64_t m = msk[q]; m; m &= m - 1) {
+            const int b = __ffsll((long long)m) - 1, t = (y0 + (b >> 3)) * a.tw + x0 + (b & 7);
+            if (!LAZY || taken(bkq[q], t)) atomicAdd(&bins[t], 1);
+          }
+        } else if (lds) {
           for (int ty = y0; ty < y1; ty++)
             for (int tx = x0; tx < x1; tx++) {
               const int t = ty * a.tw + tx;
@@ -165,15 +173,22 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
     const int x0 = rx[q] & 0xffff, x1 = rx[q] >> 16, y0 = ry[q] & 0xffff, y1 = ry[q] >> 16;
     const uint64_t hi = (uint64_t)__float_as_uint(a.depths[i]) << 32;
     uint32_t e = (LZ != 2 && a.nchunks) ? ebase[q] : (uint32_t)a.isect_offsets[i];
-    for (int ty = y0; ty < y1; ty++)
-      for (int tx = x0; tx < x1; tx++, e++) {
-        const int t = ty * a.tw + tx;
-        if (LAZY && !taken(bkq[q], t)) continue;
-        const int slot = (LAZY || lds) ? atomicAdd(&bins[t], 1)
-                                       : a.tile_offsets[tbase + t] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + t, 1);
-        a.keys[slot] = hi | e;
-        a.gid_of_emit[e] = g;
+    auto put = [&](int t) {
+      if (LAZY && !taken(bkq[q], t)) return;
+      const int slot = (LAZY || lds) ? atomicAdd(&bins[t], 1)
+                                     : a.tile_offsets[tbase + t] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + t, 1);
+      a.keys[slot] = hi | e;
+      a.gid_of_emit[e] = g;
+    };
+    if (msk[q]) {  // the emission index counts the instance's BINNED tiles in ascending bit order (both lazy launches alike)
+      for (uint64_t m = msk[q]; m; m &= m - 1, e++) {
+        const int b = __ffsll((long long)m) - 1;
+        put((y0 + (b >> 3)) * a.tw + x0 + (b & 7));
       }
+      continue;
+    }
+    for (int ty = y0; ty < y1; ty++)
+      for (int tx = x0; tx < x1; tx++, e++) put(ty * a.tw + tx);
   }
 }
 
@@ -491,6 +506,7 @@ int fill_emit_args(EmitArgs &e, const D4gsDims *dims, const D4gsProjOut *proj, c
   e.isect_offsets = proj->isect_offsets;
   e.isect_offsets_out = proj->isect_offsets, e.chunk_base = proj->scan_ws, e.nchunks = d4gs_fused_scan_chunks(dims);
   e.tile_cursor = proj->tile_counts;
+  e.tile_masks = (dims->flags & D4GS_EXACT_TILES) ? proj->tile_masks : nullptr;
   e.tile_offsets = proj->tile_offsets;
   e.keys = isect->keys;
   e.gid_of_emit = isect->gid_of_emit;

@@ -175,6 +175,7 @@ int d4gs_query_sizes(const D4gsDims *d, D4gsSizes *z) {
   z->lazy_ws = d4gs_lazy_ws_elems((int)S, (int)(tw * th));
   z->tiles_x = (int32_t)tw, z->tiles_y = (int32_t)th, z->channels = (int32_t)nch;
   z->blend_bases = d->G > 0 ? S * (int64_t)d->K * 16 : 0;
+  z->tile_masks = SN;
   return D4GS_OK;
 }
 

@@ -210,6 +210,27 @@ __device__ __forceinline__ void tight_rect(float mx, float my, float opac, float
   if (x1 == x0 || y1 == y0) x1 = x0, y1 = y0;
 }
 
+// D4GS_EXACT_TILES: does the ellipse sigma(p) = (a u^2 + c v^2) / 2 + b u v <= tau, (u, v) = p - centre, reach the rectangle of pixel
+// centres [X0, X1] x [Y0, Y1]?  sigma is convex: if the centre is outside the rectangle the minimum over it lies on an edge facing the
+// centre, where sigma is a 1-D parabola - minimise it, clamp to the edge, evaluate.  tau is tight_rect's (1 % + 0.02 margin): the
+// continuous rectangle is a superset of its pixel centres, so no tile holding a pixel with alpha >= 1/255 is ever dropped.
+__device__ __forceinline__ bool d4gs_ellipse_hits_rect(float mx, float my, float a, float b, float c, float tau, float X0, float X1,
+                                                       float Y0, float Y1) {
+  const float U0 = X0 - mx, U1 = X1 - mx, V0 = Y0 - my, V1 = Y1 - my;
+  const float uc = fminf(fmaxf(0.f, U0), U1), vc = fminf(fmaxf(0.f, V0), V1);  // the rectangle's point nearest to the centre, per axis
+  if (uc == 0.f && vc == 0.f) return true;
+  float best = 3.0e38f;
+  if (uc != 0.f) {  // the vertical edge u = uc: v* = -b uc / c
+    const float v = fminf(fmaxf(-b * uc * __builtin_amdgcn_rcpf(c), V0), V1);
+    best = 0.5f * (a * uc * uc + c * v * v) + b * uc * v;
+  }
+  if (vc != 0.f) {  // the horizontal edge v = vc: u* = -b vc / a
+    const float u = fminf(fmaxf(-b * vc * __builtin_amdgcn_rcpf(a), U0), U1);
+    best = fminf(best, 0.5f * (a * u * u + c * vc * vc) + b * u * vc);
+  }
+  return best <= tau * 1.001f + 1e-4f;  // (the clamped 1-D minimiser is computed with an approximate reciprocal: a hair of slack)
+}
+
 // camera constants, uniform across the grid (passed by value as a kernel argument -> SGPRs)
 struct Cam {
   float R[9];  // world->camera rotation

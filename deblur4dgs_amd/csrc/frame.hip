@@ -57,6 +57,7 @@ FrameBufs carve(const D4gsDims *d, int64_t cap, void *ws) {
   b.proj.tile_offsets = c.take<int32_t>(z.tile_offsets), b.proj.scan_ws = c.take<int32_t>(z.scan_ws);
   b.proj.lazy_ws = (d->flags & D4GS_LAZY_SORT) ? c.take<int32_t>(z.lazy_ws) : nullptr;
   b.proj.blend_bases = z.blend_bases > 0 ? c.take<float>(z.blend_bases) : nullptr;
+  b.proj.tile_masks = (d->flags & D4GS_EXACT_TILES) ? c.take<uint64_t>(z.tile_masks) : nullptr;
   b.isect.keys = c.take<uint64_t>(m), b.isect.gid_of_emit = c.take<int32_t>(m);
   b.isect.sorted_gid = c.take<int32_t>(m), b.isect.sorted_emit = c.take<int32_t>(m);
   b.raster.last_ids = c.take<int32_t>(z.last_ids), b.raster.final_T = c.take<float>(z.final_T);

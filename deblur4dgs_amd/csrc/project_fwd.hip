@@ -22,6 +22,8 @@ struct FwdArgs {
   D4gsProjOut out;
   int tw, th;
   int count_apart;  // 1: k_count_tiles does the tile counting / ranking (LDS-aggregated), 0: this kernel's global atomics
+  int use_table;    // 1: out.blend_bases was filled by k_bases_table in front of this kernel - the blended bases are read from it with
+                    //    scalar loads (no LDS slab); 0: every block blends its own LDS slab, block 0 also publishes the table for the backward
 };
 
 // time-blended bases: Bs[s][k][0:3] = transl, [3:9] = 6-D rotation   (params.py:152-177; w uses the clamped floor)
@@ -46,6 +48,8 @@ __device__ __forceinline__ void preblend_bases(const FwdArgs &a, float *Bs) {
   }
 }
 
+template <bool XT /* D4GS_EXACT_TILES: the wave-cooperative per-tile ellipse test (its own instantiation: 88 instead of 64 VGPRs) */,
+          bool TAB /* FwdArgs.use_table: blended bases from the global table (scalar loads) instead of the block's LDS slab */>
 __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const D4gsDims &d = a.d;
@@ -64,18 +68,15 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
     const int64_t nl = d4gs_lazy_ws_elems(S, a.tw * a.th);
     for (int64_t z = g; z < nl; z += (int64_t)gridDim.x * D4GS_PROJ_BLOCK) a.out.lazy_ws[z] = 0;
   }
-#ifdef PF_BASES_TABLE  // (A/B) the table was built by a launch in front of this kernel: scalar loads below, no LDS slab
   typedef const __attribute__((address_space(4))) float *cfloat_p;
-#else
-  if (dyn_block) preblend_bases(a, Bs);
-  if (blockIdx.x == 0 && dyn_block && a.out.blend_bases) {  // the table k_project_bwd reads with scalar loads (include/d4gs.h)
+  if (dyn_block && !TAB) preblend_bases(a, Bs);
+  if (blockIdx.x == 0 && dyn_block && !TAB && a.out.blend_bases) {  // the table k_project_bwd reads with scalar loads (include/d4gs.h)
     __syncthreads();
     for (int idx = tid; idx < S * K * 16; idx += D4GS_PROJ_BLOCK) {
       const int j = idx & 15, sk = idx >> 4;
       a.out.blend_bases[idx] = j < 9 ? Bs[sk * 9 + j] : 0.f;
     }
   }
-#endif
 
   const bool active = g < N;
   const bool raw = d.flags & D4GS_RAW_PARAMS;
@@ -124,27 +125,39 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
 
   // each wave walks the sub-samples from a different start, so resident waves hit all S*tiles counters at once
   const int rot = __builtin_amdgcn_readfirstlane((blockIdx.x * (D4GS_PROJ_BLOCK / 64) + (tid >> 6)) % S);
+  constexpr bool exact_tiles = XT;
+  __shared__ int xt_pre[XT ? D4GS_PROJ_BLOCK : 1];        // exclusive prefix of the wave's candidate (instance, tile) pairs
+  __shared__ float4 xt_rec[XT ? D4GS_PROJ_BLOCK : 1][2];  // per instance: centre, conic, tau, packed rectangle origin / width
+  __shared__ uint32_t xt_mask[XT ? D4GS_PROJ_BLOCK : 1][2];
   for (int it = 0; it < S; it++) {
-    if (!active) continue;
+    if constexpr (!XT) {  // (the plain instantiation keeps its round-4 control flow - and its 64 VGPRs: idle lanes leave at once)
+      if (!active) continue;
+    }
     const int s = (it + rot) % S;
+    // what the lane's instance leaves behind for the (wave-cooperative) exact tile test and the stores after it
+    int cnt = 0, radius_out = 0;
+    int2 rect = make_int2(0, 0);
+    float m2x = 0.f, m2y = 0.f, dep = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    if (active) {
     float mw[3], Rm[9];
     if (g < G) {
       float v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef PF_BASES_TABLE
-      for (int k = 0; k < K; k++) {
-        float c = cf[k * D4GS_PROJ_BLOCK + tid];
-        cfloat_p Bk = (cfloat_p)(uintptr_t)a.out.blend_bases + ((size_t)s * K + k) * 16;
+      if constexpr (TAB) {  // many bases: rows of the global table through the scalar cache (see d4gs_project_fwd_impl)
+        for (int k = 0; k < K; k++) {
+          float c = cf[k * D4GS_PROJ_BLOCK + tid];
+          cfloat_p Bk = (cfloat_p)(uintptr_t)a.out.blend_bases + ((size_t)s * K + k) * 16;
 #pragma unroll
-        for (int j = 0; j < 9; j++) v9[j] += c * Bk[j];
-      }
-#else
-      const float *B = Bs + s * K * 9;
-      for (int k = 0; k < K; k++) {
-        float c = cf[k * D4GS_PROJ_BLOCK + tid];
+          for (int j = 0; j < 9; j++) v9[j] += c * Bk[j];
+        }
+      } else {
+        const float *B = Bs + s * K * 9;
+        for (int k = 0; k < K; k++) {
+          float c = cf[k * D4GS_PROJ_BLOCK + tid];
 #pragma unroll
-        for (int j = 0; j < 9; j++) v9[j] += c * B[k * 9 + j];
+          for (int j = 0; j < 9; j++) v9[j] += c * B[k * 9 + j];
+        }
       }
-#endif
       GS6 gs;
       gram_schmidt(v9 + 3, gs);
       float Rd[9] = {gs.x[0], gs.y[0], gs.z[0], gs.x[1], gs.y[1], gs.z[1], gs.x[2], gs.y[2], gs.z[2]};
@@ -164,13 +177,9 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       float t2 = RT[8] * mw[0] + RT[9] * mw[1] + RT[10] * mw[2] + RT[11];
       mw[0] = t0, mw[1] = t1, mw[2] = t2;
     }
-    const size_t i = (size_t)s * N + g;
     ProjOut p;
     project_instance(cam, mw, Rm, sc, d, p);
-    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-    float m2x = 0.f, m2y = 0.f, dep = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
-    int cnt = 0;
-    int2 rect = make_int2(0, 0);
+    radius_out = p.radius;
     if (p.radius > 0) {
       float idet = 1.f / p.det;
       ca = p.c * idet, cb = -p.b * idet, cc = p.a * idet;
@@ -182,13 +191,78 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       if (d.flags & D4GS_EXACT_CULL) tight_rect(m2x, m2y, opac, p.a, p.c, x0, y0, x1, y1);
       rect = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       cnt = (x1 - x0) * (y1 - y0);
+    }
+    }  // active
+    // ---- D4GS_EXACT_TILES: which tiles of the tight rectangle does the alpha >= 1/255 ellipse reach?  The (instance, tile) pairs of
+    // the wave's 64 instances are spread over its lanes (a lane-private loop over the rectangle diverges: rectangles of 1 ... 64 tiles
+    // in one wave - the round-4 attempt inside k_count_tiles / k_emit paid 300 us for it on cfg5); rectangles of 2 ... 64 tiles, at
+    // most 8 wide and 8 tall, get a mask; the rest keep their whole rectangle (mask 0).
+    uint64_t mask = 0;
+    if constexpr (exact_tiles) {
+      const int x0 = rect.x & 0xffff, x1 = rect.x >> 16, y0 = rect.y & 0xffff, y1 = rect.y >> 16;
+      const int w = x1 - x0, h = y1 - y0;
+      const bool cand = cnt >= 2 && w <= 8 && h <= 8;
+      const int np = cand ? cnt : 0;
+      const int lane = tid & 63, wbase = tid & ~63;
+      int inc = np;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+      }
+      const int total = __shfl(inc, 63);
+      if (total > 0) {  // (wave-uniform)
+        xt_pre[tid] = inc - np;
+        // conic of the BLURRED covariance = the geom record's; tau as tight_rect computes it
+        const float tau = __logf(255.f * opac) * 1.01f + 0.02f;
+        xt_rec[tid][0] = make_float4(m2x, m2y, ca, cb);
+        xt_rec[tid][1] = make_float4(cc, tau, __int_as_float(x0 | (y0 << 16)), __int_as_float(w));
+        xt_mask[tid][0] = 0u, xt_mask[tid][1] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (int pp = lane; pp < total; pp += 64) {
+          int lo = 0;  // the last instance whose prefix is <= pp (instances without pairs share their successor's prefix)
+#pragma unroll
+          for (int step = 32; step > 0; step >>= 1)
+            if (xt_pre[wbase + lo + step] <= pp) lo += step;
+          const int q = pp - xt_pre[wbase + lo];
+          const float4 r0 = xt_rec[wbase + lo][0], r1 = xt_rec[wbase + lo][1];
+          const int ww = __float_as_int(r1.w), xy = __float_as_int(r1.z);
+          const int ry = (int)(((float)q + 0.5f) * __builtin_amdgcn_rcpf((float)ww));  // q / ww for q < 64, ww <= 8
+          const int rx = q - ry * ww;
+          const int tx = (xy & 0xffff) + rx, ty = (xy >> 16) + ry;
+          const float X0 = (float)(tx * D4GS_TILE) + 0.5f, Y0 = (float)(ty * D4GS_TILE) + 0.5f;
+          const float X1 = fminf(X0 + (float)(D4GS_TILE - 1), (float)d.width - 0.5f), Y1 = fminf(Y0 + (float)(D4GS_TILE - 1), (float)d.height - 0.5f);
+          if (d4gs_ellipse_hits_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, X0, X1, Y0, Y1)) {
+            const int bit = ry * 8 + rx;
+            atomicOr(&xt_mask[wbase + lo][bit >> 5], 1u << (bit & 31));
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (cand) {
+          mask = (uint64_t)xt_mask[tid][0] | ((uint64_t)xt_mask[tid][1] << 32);
+          cnt = __popcll(mask);
+          if (cnt == 0) rect = make_int2(0, 0);  // (the ellipse reaches no pixel centre of any tile: nothing to bin)
+        }
+        __builtin_amdgcn_wave_barrier();  // the arrays are rewritten by the next pass
+      }
+    }
+    if (!active) continue;
+    const size_t i = (size_t)s * N + g;
+    if (!a.count_apart && cnt > 0) {  // tile grids too big for the LDS histogram: plain global atomics
       int *tc = a.out.tile_counts + (size_t)s * a.tw * a.th;
-      if (!a.count_apart) {  // tile grids too big for the LDS histogram: plain global atomics
+      const int x0 = rect.x & 0xffff, x1 = rect.x >> 16, y0 = rect.y & 0xffff, y1 = rect.y >> 16;
+      if (mask) {
+        for (uint64_t m = mask; m; m &= m - 1) {
+          const int b = __ffsll((long long)m) - 1;
+          atomicAdd(tc + (y0 + (b >> 3)) * a.tw + x0 + (b & 7), 1);
+        }
+      } else {
         for (int ty = y0; ty < y1; ty++)
           for (int tx = x0; tx < x1; tx++) atomicAdd(tc + ty * a.tw + tx, 1);
       }
     }
-    a.out.radii[i] = p.radius;
+    if (exact_tiles) a.out.tile_masks[i] = mask;
+    a.out.radii[i] = radius_out;
     *reinterpret_cast<float2 *>(a.out.means2d + i * 2) = make_float2(m2x, m2y);
     a.out.depths[i] = dep;
     a.out.conics[i * 3] = ca;
@@ -378,7 +452,8 @@ template <int COUNT_PER_THREAD, bool LAZY>
 __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__restrict__ tile_rects,
                                                               const int *__restrict__ tiles_touched, int N, int S, int tw,
                                                               int th, int *__restrict__ tile_counts, int *__restrict__ chunk_sums,
-                                                              const float *__restrict__ depths, LazyWs lazy) {
+                                                              const float *__restrict__ depths, LazyWs lazy,
+                                                              const uint64_t *__restrict__ tile_masks /* D4GS_EXACT_TILES or NULL */) {
   extern __shared__ int hist[];  // [tiles] (+ LAZY: [tiles][nb] per depth bucket)
   __shared__ int wsum[COUNT_THREADS / 64];
   const int tiles = tw * th, tid = threadIdx.x;
@@ -399,6 +474,15 @@ __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__rest
     const int2 rc = *reinterpret_cast<const int2 *>(tile_rects + i * 2);
     const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
     const int bk = LAZY ? d4gs_depth_bucket(depths[i], zlo, zhi, lazy.nb) : 0;
+    const uint64_t mask = tile_masks ? tile_masks[i] : 0;
+    if (mask) {  // D4GS_EXACT_TILES: the tiles the ellipse reaches, bit (ty - y0) * 8 + (tx - x0)
+      for (uint64_t m = mask; m; m &= m - 1) {
+        const int b = __ffsll((long long)m) - 1, t = (y0 + (b >> 3)) * tw + x0 + (b & 7);
+        atomicAdd(&hist[t], 1);
+        if (LAZY) atomicAdd(&hist2[t * lazy.nb + bk], 1);
+      }
+      continue;
+    }
     for (int ty = y0; ty < y1; ty++)
       for (int tx = x0; tx < x1; tx++) {
         atomicAdd(&hist[ty * tw + tx], 1);
@@ -618,6 +702,10 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
     d4gs_set_error("S*K too large for the LDS-resident bases (S=%d K=%d)", dims->S, dims->K);
     return D4GS_EINVAL;
   }
+  if ((dims->flags & D4GS_EXACT_TILES) && (!out->tile_masks || !(dims->flags & D4GS_EXACT_CULL))) {
+    d4gs_set_error("D4GS_EXACT_TILES needs D4gsProjOut.tile_masks and D4GS_EXACT_CULL (the masks refine the tight rectangle)");
+    return D4GS_EINVAL;
+  }
   const int blocks = (dims->N + D4GS_PROJ_BLOCK - 1) / D4GS_PROJ_BLOCK;
   const size_t hist_bytes = sizeof(int) * (size_t)a.tw * a.th;
   static const bool force_in_kernel = getenv("D4GS_COUNT_IN_PROJECT") != nullptr;  // test hook for the fallback
@@ -630,17 +718,24 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
       return D4GS_ELAUNCH;
     }
   }
-#ifdef PF_BASES_TABLE
-  if (dims->G > 0) {
-    if (!out->blend_bases) {
-      d4gs_set_error("PF_BASES_TABLE build: D4gsProjOut.blend_bases is required");
-      return D4GS_EINVAL;
-    }
+  // Many motion bases (K >= 10: cfg5's 12, the reference's 20): the S x K x 9 blended values are built ONCE by a small launch in front
+  // and every lane's 9 K multiply-adds per sub-sample take them as scalar operands instead of LDS broadcast reads - refdefault 73.4 ->
+  // 61.2 us, cfg5 382 -> 357; at K = 6 the saving (1.5 us) is less than the launch (profiles/r05_ab_bases_table.txt).
+  // D4GS_FWD_TABLE=0 / 1 forces it off / on (A/B).
+  static const int tab_env = []() { const char *e = getenv("D4GS_FWD_TABLE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  a.use_table = dims->G > 0 && out->blend_bases && (tab_env < 0 ? dims->K >= 10 : tab_env == 1);
+  if (a.use_table) {
     int rc0 = d4gs_bases_table_launch(dims, in, out->blend_bases, stream);
     if (rc0) return rc0;
   }
-#endif
-  D4GS_LAUNCH("k_project_fwd", k_project_fwd, dim3(blocks), dim3(D4GS_PROJ_BLOCK), lds, stream, a);
+  {
+    const bool xt = dims->flags & D4GS_EXACT_TILES;
+    const void *fn = xt ? (a.use_table ? (const void *)k_project_fwd<true, true> : (const void *)k_project_fwd<true, false>)
+                        : (a.use_table ? (const void *)k_project_fwd<false, true> : (const void *)k_project_fwd<false, false>);
+    ProfScope _ps("k_project_fwd", stream);
+    void *kargs[] = {(void *)&a};
+    (void)hipLaunchKernel(fn, dim3(blocks), dim3(D4GS_PROJ_BLOCK), kargs, lds, stream);
+  }
   int rc = d4gs_check_launch("k_project_fwd");
   if (rc) return rc;
   if (a.count_apart) {
@@ -661,7 +756,8 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
     if (cbytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_count_tiles<PT_, LZ_>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); /* (+ the kernel's static LDS <= 160 KB) */ \
     D4GS_LAUNCH("k_count_tiles", (k_count_tiles<PT_, LZ_>), dim3(cblocks), dim3(COUNT_THREADS), cbytes, stream,              \
                 (const int *)out->tile_rects, (const int *)out->tiles_touched, dims->N, dims->S, a.tw, a.th, out->tile_counts, \
-                fused_chunks ? out->scan_ws : (int *)nullptr, (const float *)out->depths, lw);                                \
+                fused_chunks ? out->scan_ws : (int *)nullptr, (const float *)out->depths, lw,                                 \
+                (const uint64_t *)((dims->flags & D4GS_EXACT_TILES) ? out->tile_masks : nullptr));                            \
   } while (0)
     if (pt == 1 && lazy) D4GS_COUNT(1, true);
     else if (pt == 1) D4GS_COUNT(1, false);

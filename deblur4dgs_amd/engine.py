@@ -61,6 +61,10 @@ class RenderCfg:
     #                                  render by `resolve_lazy` (D4GS_LAZY_SORT=auto, the default: on when the previous render of the
     #                                  shape measured < 50 % live rows and lists of >= 1000 keys on average)
     near_target: int = 0  # keys the near part of a list is aimed at (0: the library's 1024)
+    exact_tiles: bool | None = None  # D4GS_EXACT_TILES (include/d4gs.h): bin a splat only into the tiles of its tight rectangle that its
+    #                                  alpha >= 1/255 ellipse reaches.  Same image and gradients bit for bit, shorter lists; the test costs the
+    #                                  projection ~1 instruction per candidate pair and lane, so None (D4GS_EXACT_TILES=auto) turns it on from
+    #                                  EXACT_TILES_FROM intersections per instance, measured by the previous render of the shape
 
     @property
     def DP(self) -> int:
@@ -76,7 +80,9 @@ class RenderCfg:
 
     def dims(self) -> L.Dims:
         return L.Dims(self.N, self.G, self.K, self.T, self.S, self.D, self.width, self.height, self.depth_mode,
-                      self.flags | (L.EXACT_CULL if self.exact_cull else 0) | (L.LAZY_SORT if self.lazy_sort else 0), self.n_sigmoid, self.near_plane, self.far_plane, self.eps2d, self.radius_clip)
+                      self.flags | (L.EXACT_CULL if self.exact_cull else 0) | (L.LAZY_SORT if self.lazy_sort else 0)
+                      | (L.EXACT_TILES if (self.exact_tiles and self.exact_cull) else 0), self.n_sigmoid, self.near_plane, self.far_plane,
+                      self.eps2d, self.radius_clip)
 
 
 @dataclass
@@ -202,8 +208,28 @@ assert LAZY_SORT in ("0", "1", "auto"), f"D4GS_LAZY_SORT={LAZY_SORT!r}"
 LAZY_AUTO_LIVE, LAZY_AUTO_KEYS = (float(x) for x in os.environ.get("D4GS_LAZY_AUTO", "0.5,1000").split(","))
 
 
+# "auto" (default) | "0" | "1"
+EXACT_TILES = os.environ.get("D4GS_EXACT_TILES", "auto")
+assert EXACT_TILES in ("0", "1", "auto"), f"D4GS_EXACT_TILES={EXACT_TILES!r}"
+EXACT_TILES_FROM = float(os.environ.get("D4GS_EXACT_TILES_FROM", "3.0"))  # intersections per (sub-sample, Gaussian) instance
+_XT_ON: dict = {}  # size key -> bool: the shape's current choice (hysteresis: the test itself shortens the lists it is decided from)
+
+
 def resolve_lazy(cfg, dev):
-    """Fix cfg.lazy_sort / cfg.near_target for one render (once: forward and backward must agree on D4gsDims.flags)."""
+    """Fix cfg.lazy_sort / cfg.near_target / cfg.exact_tiles for one render (once: forward and backward must agree on D4gsDims.flags)."""
+    if cfg.exact_tiles is None:
+        cfg.exact_tiles = EXACT_TILES == "1"
+        if EXACT_TILES == "auto":  # the list capacity of the shape is 1.25 x the previous render's count (+ 4096)
+            key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
+            guess = _guess_get(key)
+            per_inst = ((guess[0] - 4096) / 1.25 / (cfg.S * max(cfg.N, 1))) if guess else 0.0
+            with _SIZE_LOCK:
+                on = _XT_ON.get(key, False)
+                on = per_inst >= (0.6 * EXACT_TILES_FROM if on else EXACT_TILES_FROM)  # on from 3 per instance, off again below 1.8
+                if len(_XT_ON) > 4 * _SIZE_GUESS_MAX:
+                    _XT_ON.clear()
+                _XT_ON[key] = on
+            cfg.exact_tiles = on
     if cfg.lazy_sort is None:
         cfg.lazy_sort = LAZY_SORT == "1"
         if LAZY_SORT == "auto":
@@ -426,6 +452,7 @@ class ProjectFn(torch.autograd.Function):
             tile_offsets=torch.empty(S * tw * th + 1, **i32), n_isect=torch.empty(4, dtype=torch.int64, device=dev),
             scan_ws=torch.empty(lib.d4gs_scan_ws_elems(S * N), **i32),
             blend_bases=torch.empty(S * cfg.K * 16, **f32) if cfg.G > 0 else None,  # the backward's scalar-load table (include/d4gs.h)
+            tile_masks=torch.empty(S * N, dtype=torch.int64, device=dev) if (cfg.exact_tiles and cfg.exact_cull) else None,
         )
         dims = cfg.dims()
         pin, pout = _proj_structs(st)

@@ -87,6 +87,7 @@ def render_exposure(
     fused: bool = False,
     lazy_sort: bool | None = None,
     near_target: int = 0,
+    exact_tiles: bool | None = None,
 ):
     """-> dict(renders [S,H,W,D'], alphas [S,H,W,1], blended [H,W,D'] | None, acc [H,W] | None,
                means2d [S,N,2], radii [S,N], state).
@@ -102,7 +103,7 @@ def render_exposure(
                     D=colors.shape[-1], width=width, height=height,
                     depth_mode=L.DEPTH_ED if return_depth else L.DEPTH_NONE, flags=flags, n_sigmoid=n_sigmoid,
                     exact_cull=exact_cull, grad_arena=grad_arena, control_stats=control_stats,
-                    deferred_size_check=deferred_size_check, lazy_sort=lazy_sort, near_target=near_target)
+                    deferred_size_check=deferred_size_check, lazy_sort=lazy_sort, near_target=near_target, exact_tiles=exact_tiles)
     if fused and frame_supported(cfg):
         # ONE autograd node over d4gs_forward / d4gs_backward: same kernels and bits as the staged chain below, a fraction
         # of its host work.  `means2d` is then a plain tensor; its gradient goes to st.xys_sink / st.v_means2d.

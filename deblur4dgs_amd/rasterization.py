@@ -43,6 +43,7 @@ def rasterization(
     exact_cull: bool = True,
     lazy_sort: bool | None = None,
     near_target: int = 0,
+    exact_tiles: bool | None = None,
     **_ignored,
 ):
     if viewmats.shape[0] != 1 or Ks.shape[0] != 1:
@@ -59,9 +60,12 @@ def rasterization(
     # tile lists (engine.channel_chunks), like gsplat's `channel_chunk`
     if lazy_sort is None:  # `info["flatten_ids"]` is part of this seam: lazy lists (unsorted behind a tile's last contributor) only on request
         lazy_sort = engine.LAZY_SORT == "1"
+    if exact_tiles is None:  # likewise `tiles_per_gauss` / the lists: the per-tile ellipse test only on request (or D4GS_EXACT_TILES=1)
+        exact_tiles = engine.EXACT_TILES == "1"
     cfg = RenderCfg(N=N, G=0, K=0, T=0, S=1, D=colors.shape[-1], width=width, height=height,
                     depth_mode=_MODES[render_mode], flags=0, near_plane=near_plane, far_plane=far_plane, eps2d=eps2d,
-                    radius_clip=radius_clip, exact_cull=exact_cull, lazy_sort=lazy_sort, near_target=near_target)
+                    radius_clip=radius_clip, exact_cull=exact_cull, lazy_sort=lazy_sort, near_target=near_target,
+                    exact_tiles=exact_tiles)
     rc, ra, means2d, radii, st = render_instances(cfg, means, quats, scales, opacities, colors, None, None, None,
                                                   None, None, viewmats[0], Ks[0], bg)
     tw, th = cfg.tiles

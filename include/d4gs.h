@@ -52,6 +52,11 @@ enum { /* D4gsDims.flags */
                            emitted and sorted - and the tile composited again over its whole list - only if the tile did not
                            saturate within the near part (d4gs_raster_fwd does that between its two passes).  Same lists where they matter, same image and gradients bit for bit;
                            needs D4gsProjOut.lazy_ws. */
+  D4GS_EXACT_TILES = 16, /* (v305) on top of D4GS_EXACT_CULL: inside the tight rectangle, bin a splat only into the tiles its alpha >= 1/255
+                           ellipse actually reaches (the corner tiles of a 2 x 2 ... 8 x 8 rectangle usually are not reached: 15 - 40 % shorter
+                           lists at 720p).  The per-tile test runs in d4gs_project_fwd, the pairs of a wave's 64 instances spread over its
+                           lanes, and leaves a 64-bit tile mask per instance (D4gsProjOut.tile_masks, required with the flag).  Same images
+                           and gradients bit for bit; tiles_touched / the lists get shorter.  Pays from ~3 tiles per instance on. */
   D4GS_EXACT_CULL = 4   /* bin a splat only into tiles that hold a pixel with alpha >= 1/255 (tight ellipse
                            sigma <= ln(255*opacity), intersected with gsplat's 3-sigma tile rectangle).  Pixels in
                            the dropped tiles would fail gsplat's alpha test anyway, so images and gradients are
@@ -124,6 +129,9 @@ typedef struct D4gsProjOut {
   float *blend_bases;      /* [S,K,16] or NULL (v305, appended): the time-blended motion bases of the S sub-samples (row k: transl 3,
                               6-D rotation 6, 7 pad floats), written by d4gs_project_fwd when G > 0 and read by d4gs_project_bwd with
                               scalar loads.  NULL: d4gs_project_bwd builds the table itself (one small launch more). */
+  uint64_t *tile_masks;    /* [S*N] (v305, appended; needed with D4GS_EXACT_TILES only): bit (ty - y0) * 8 + (tx - x0) = tile (tx, ty) of the
+                              instance's packed rectangle is binned; 0 = no mask, the whole rectangle is (rectangles wider or taller
+                              than 8 tiles, single tiles, flag off) */
 } D4gsProjOut;
 
 typedef struct D4gsIsect {
@@ -235,6 +243,7 @@ typedef struct {
   int64_t lazy_ws;                                               /* D4gsProjOut.lazy_ws (int32 elements; needed with D4GS_LAZY_SORT only) */
   int32_t tiles_x, tiles_y, channels;                            /* tile grid; D + depth channel */
   int64_t blend_bases;                                           /* D4gsProjOut.blend_bases (v305, appended; 0 when G == 0) */
+  int64_t tile_masks;                                            /* D4gsProjOut.tile_masks (uint64 elements; needed with D4GS_EXACT_TILES) */
 } D4gsSizes;
 D4GS_API int d4gs_query_sizes(const D4gsDims *dims, D4gsSizes *sizes);
 

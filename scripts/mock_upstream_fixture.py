@@ -22,7 +22,7 @@ from oracle import deform, raster  # noqa: E402
 from tests.golden import gen_upstream_fixture as G  # noqa: E402
 
 
-def run_oracle(inp, W, H, mode, seed):
+def run_oracle(inp, W, H, mode, seed, ed_weight=True):
     t = {k: v.double().clone().requires_grad_(k != "K") for k, v in inp.items() if torch.is_tensor(v)}
     D = t["colors"].shape[-1]
     bg = torch.linspace(0.1, 0.9, D, dtype=torch.float64)
@@ -31,6 +31,8 @@ def run_oracle(inp, W, H, mode, seed):
     info["means2d"].retain_grad()
     g = torch.Generator().manual_seed(seed)
     w_c = torch.randn((1, *rc.shape), generator=g)
+    if not ed_weight:
+        w_c[..., D:] = 0.0
     w_a = torch.randn((1, *ra.shape), generator=g)
     ((rc[None] * w_c.double()).sum() + (ra[None] * w_a.double()).sum()).backward()
     f32 = lambda x: x.detach().float().numpy()
@@ -54,7 +56,7 @@ def main(out_dir):
         for k, v in run_oracle(inp, W, H, mode, seed).items():
             f[f"{name}|{k}"] = v
     for name, sc in G.known_answer_scenes().items():
-        for k, v in run_oracle(sc, sc["W"], sc["H"], "RGB+ED", 7).items():
+        for k, v in run_oracle(sc, sc["W"], sc["H"], "RGB+ED", 7, ed_weight=False).items():
             f[f"{name}|{k}"] = v
     np.savez_compressed(os.path.join(out_dir, "upstream_gsplat.npz"), **f)
 

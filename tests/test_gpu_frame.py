@@ -64,6 +64,41 @@ def test_one_call_path_equals_the_staged_chain_bitwise(N, G, K_, S, W, H, D, sub
     assert float(out[True]["g_means"].abs().max()) > 0 and float(out[True]["m2g"].abs().max()) > 0
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_exact_tiles_through_the_frame_paths(fused, monkeypatch):
+    """D4GS_EXACT_TILES through d4gs_forward / d4gs_backward (the mask buffer lives in the frame workspace) and through the staged
+    chain, on a dynamic S = 3 scene of splats a few tiles wide: blended frame, sub-sample images, radii and every leaf gradient are
+    BITWISE those of whole rectangles; the lists shrink.  Then the `auto` rule: on from 3 intersections per instance (the previous
+    render's count), with hysteresis, and the same bits again."""
+    from deblur4dgs_amd import engine
+
+    monkeypatch.setenv("D4GS_SEG", "0")
+    dev = torch.device("cuda:0")
+    N, G, K_, S, W, H = 6000, 4000, 4, 3, 256, 160
+    sc = make_scene(N, G, K_, S, W, H, seed=35)
+    sc["scales"] = sc["scales"] + 2.0  # exp(2) = 7.4 x: rectangles of 2 x 2 ... 4 x 4 tiles
+    K = sc["K"].to(dev)
+    g = torch.Generator().manual_seed(7)
+    wb, wa = torch.randn(H, W, 4, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
+    out = {}
+    for xt in (False, True, None):
+        if xt is None:  # auto: the previous renders of this shape left ~4 intersections per instance -> on
+            monkeypatch.setattr(engine, "EXACT_TILES", "auto")
+        L = _leaves(sc, dev)
+        r = _render(L, K, W, H, fused, exact_tiles=xt)
+        ((r["blended"] * wb).sum() + (r["acc"] * wa).sum()).backward()
+        torch.cuda.synchronize()
+        out[xt] = dict(blended=r["blended"], renders=r["renders"], alphas=r["alphas"], radii=r["radii"], n=r["state"].n_isect,
+                       on=r["state"].cfg.exact_tiles, **{f"g_{k}": v.grad for k, v in L.items() if v is not None})
+    assert out[False]["on"] is False and out[True]["on"] is True and out[None]["on"] is True
+    assert out[False]["n"] > 3 * S * N * 0.8 and out[True]["n"] < 0.93 * out[False]["n"] and out[None]["n"] == out[True]["n"]
+    for k, a in out[False].items():
+        if k in ("n", "on"):
+            continue
+        for other in (True, None):
+            assert torch.equal(a.detach(), out[other][k].detach()), (k, other)
+
+
 def test_one_call_path_unblended_and_size_protocol():
     """blend=False (what exposure sharding renders), a cold size guess (the counting call), a warm one, and an overflowing
     deferred one - the protocol is the staged chain's."""

@@ -22,7 +22,7 @@ GFLIPS = FLIPS
 VTOL = 1e-4     # viewmat gradient: a sum over all Gaussians (measured <= 2e-5); no flip allowance
 
 
-def _run_gpu(inp, W, H, mode, bg, requires_grad=False, exact_cull=True):
+def _run_gpu(inp, W, H, mode, bg, requires_grad=False, exact_cull=True, **kw):
     from deblur4dgs_amd.rasterization import rasterization
 
     dev = torch.device("cuda:0")
@@ -32,7 +32,7 @@ def _run_gpu(inp, W, H, mode, bg, requires_grad=False, exact_cull=True):
             t[k].requires_grad_()
     rc, ra, info = rasterization(t["means"], t["quats"], t["scales"], t["opac"], t["colors"], t["V"][None],
                                  t["K"][None], W, H, backgrounds=None if bg is None else bg.to(dev)[None].float(),
-                                 render_mode=mode, exact_cull=exact_cull)
+                                 render_mode=mode, exact_cull=exact_cull, **kw)
     return rc, ra, info, t
 
 
@@ -212,6 +212,47 @@ def test_exact_cull_changes_nothing(mode, D, monkeypatch):
     assert torch.equal(c0, c1) and torch.equal(a0, a1) and torch.equal(m0, m1)
     for x, y in zip(g0, g1):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("mode,D,scale_mul,lazy", [("RGB+ED", 3, 6.0, False), ("RGB", 4, 12.0, False), ("RGB+ED", 16, 8.0, False),
+                                                   ("RGB+ED", 3, 14.0, True), ("RGB+ED", 3, 30.0, False)])
+def test_exact_tiles_change_nothing_but_the_lists(mode, D, scale_mul, lazy, monkeypatch):
+    """D4GS_EXACT_TILES (include/d4gs.h): inside a splat's tight rectangle only the tiles its alpha >= 1/255 ellipse reaches are binned
+    (per-tile test in k_project_fwd, the wave's (instance, tile) pairs spread over its lanes; 64-bit mask per instance consumed by
+    k_count_tiles / k_emit).  Image, alpha and EVERY gradient must be BITWISE what the whole rectangles give, the lists must be a
+    subset of the rectangles' lists in the same depth order, and they must shrink on splats a few tiles wide.  scale_mul 30: rectangles
+    beyond 8 x 8 tiles keep their whole rectangle (mask 0) next to masked ones; lazy: the near / far emit launches count the same pairs."""
+    monkeypatch.setenv("D4GS_SEG", "0")
+    W, H, N = 256, 160, 6000
+    inp = static_inputs(N, W, H, seed=31 + D, dtype=torch.float32, D=D, scale_mul=scale_mul)
+    if lazy:
+        inp["opac"] = torch.full_like(inp["opac"], 0.97)
+    bg = torch.linspace(0.2, 0.8, D)
+    res = []
+    for xt in (False, True):
+        rc, ra, info, tg = _run_gpu(inp, W, H, mode, bg, requires_grad=True, exact_tiles=xt, lazy_sort=lazy, near_target=300)
+        info["means2d"].retain_grad()
+        g = torch.Generator().manual_seed(3)
+        w = torch.randn(rc.shape, generator=g).to(rc.device)
+        ((rc * w).sum() + ra.sum()).backward()
+        torch.cuda.synchronize()
+        offs = torch.cat([info["isect_offsets"].flatten().cpu().long(), torch.tensor([info["n_isect"]])])
+        res.append(dict(rc=rc.detach().clone(), ra=ra.detach().clone(), n=info["n_isect"], m2d=info["means2d"].grad.clone(),
+                        grads=[tg[k].grad.clone() for k in ("means", "quats", "scales", "opac", "colors", "V")],
+                        tpg=info["tiles_per_gauss"].flatten().cpu().clone(), ids=info["flatten_ids"].cpu().clone(), offs=offs,
+                        last=info["last_ids"].cpu().clone()))
+    a, b = res
+    assert torch.equal(a["rc"], b["rc"]) and torch.equal(a["ra"], b["ra"]) and torch.equal(a["m2d"], b["m2d"])
+    for x, y in zip(a["grads"], b["grads"]):
+        assert torch.equal(x, y)
+    assert b["n"] < (0.93 if scale_mul < 30 else 0.99) * a["n"], (a["n"], b["n"])  # corner tiles of 2 x 2 ... 8 x 8 rectangles go
+    assert bool((b["tpg"] <= a["tpg"]).all()) and int(b["tpg"].sum()) == b["n"]
+    if not lazy:  # every reduced list = the full list minus the dropped pairs, order kept (lazy lists are unsorted behind the last contributor)
+        for t in range(len(a["offs"]) - 1):
+            fa = a["ids"][a["offs"][t]:a["offs"][t + 1]].tolist()
+            fb = b["ids"][b["offs"][t]:b["offs"][t + 1]].tolist()
+            it = iter(fa)
+            assert all(any(x == y for y in it) for x in fb), t  # fb is a subsequence of fa
 
 
 def test_long_tile_lists_all_sort_paths():

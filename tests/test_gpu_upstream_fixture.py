@@ -96,7 +96,9 @@ def test_pose_compose_matches_real_roma():
     # product keeps roma's convention away from the angle ~ pi branch points and is compared up to sign only there
     near_pi = torch.arange(n) < 64
     assert bool((sign[~near_pi] > 0).all()), "quaternion sign convention differs from roma's away from the pi branch"
-    assert float((got * sign - want).abs().max()) <= 2e-6
+    err = (got * sign - want).abs().amax(-1)
+    assert float(err[~near_pi].max()) <= 2e-6
+    assert float(err[near_pi].max()) <= 5e-5  # angle within 1e-4 of pi: w = sqrt(1 + trace) / 2 ~ 5e-5 is formed from a cancelling fp32 sum
 
 
 def test_camera_path_matches_real_pypose():
