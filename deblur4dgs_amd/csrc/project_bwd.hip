@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
         float v9[9];
 #pragma unroll
         for (int j = 0; j < 9; j++) v9[j] = 0.f;
-#ifdef PB_PAIR  // (A/B) two table rows per iteration: half as many scalar-load waits
+        // (two table rows per iteration: half as many waits for the scalar loads - 114 -> 107.5 us on cfg2; an odd K's last
+        // iteration reads its row twice with the second coefficient 0)
         for (int k = 0; k < K; k += 2) {
           const bool two = k + 1 < K;
           const float c0 = cfl[k], c1 = two ? cfl[k + 1] : 0.f;
@@ -236,14 +237,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
 #pragma unroll
           for (int j = 0; j < 9; j++) v9[j] += c1 * r1[j];
         }
-#else
-        for (int k = 0; k < K; k++) {
-          float c = cfl[k];
-          cfloat_p Bk = PB_BROW(k);
-#pragma unroll
-          for (int j = 0; j < 9; j++) v9[j] += c * Bk[j];
-        }
-#endif
         GS6 gs;
         gram_schmidt(v9 + 3, gs);
         Rd[0] = gs.x[0], Rd[1] = gs.y[0], Rd[2] = gs.z[0];
@@ -469,7 +462,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
         vec[6] = vb[0], vec[7] = vb[1], vec[8] = vb[2];
         SB();
         // coefficient gradients: v_c[k] += B_s[k] . vec[0:9]
-#ifdef PB_PAIR
         for (int k = 0; k < K; k += 2) {
           const bool two = k + 1 < K;
           cfloat_p B0 = PB_BROW(k), B1 = PB_BROW(two ? k + 1 : k);
@@ -484,15 +476,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
           vcf[tid * KP + k] += acc0;
           if (two) vcf[tid * KP + k + 1] += acc1;
         }
-        if (false)
-#endif
-        for (int k = 0; k < K; k++) {
-          float acc = 0.f;
-          cfloat_p Bk = PB_BROW(k);
-#pragma unroll
-          for (int j = 0; j < 9; j++) acc += Bk[j] * vec[j];
-          vcf[tid * KP + k] += acc;
-        }
+
       } else {
 #pragma unroll
         for (int c = 0; c < 3; c++) ACC(c, v_mw0[c]);

@@ -50,7 +50,11 @@ __device__ __forceinline__ void preblend_bases(const FwdArgs &a, float *Bs) {
 
 template <bool XT /* D4GS_EXACT_TILES: the wave-cooperative per-tile ellipse test (its own instantiation: 88 instead of 64 VGPRs) */,
           bool TAB /* FwdArgs.use_table: blended bases from the global table (scalar loads) instead of the block's LDS slab */>
-__global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a) {
+__global__ void __launch_bounds__(D4GS_PROJ_BLOCK)
+#ifdef XT_WAVES  // (A/B) the exact-tiles instantiations at XT_WAVES waves per SIMD (6: 80 VGPRs + a 16-byte scratch frame; default: 83-85, 5 waves)
+__attribute__((amdgpu_waves_per_eu(XT ? XT_WAVES : 1, XT ? XT_WAVES : 10)))
+#endif
+k_project_fwd(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const D4gsDims &d = a.d;
   const int N = d.N, G = d.G, K = d.K, S = d.S;
@@ -144,11 +148,18 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
     if (g < G) {
       float v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       if constexpr (TAB) {  // many bases: rows of the global table through the scalar cache (see d4gs_project_fwd_impl)
-        for (int k = 0; k < K; k++) {
-          float c = cf[k * D4GS_PROJ_BLOCK + tid];
-          cfloat_p Bk = (cfloat_p)(uintptr_t)a.out.blend_bases + ((size_t)s * K + k) * 16;
+        for (int k = 0; k < K; k += 2) {  // two rows per iteration (half as many scalar-load waits), as in k_project_bwd
+          const bool two = k + 1 < K;
+          const float c0 = cf[k * D4GS_PROJ_BLOCK + tid], c1 = two ? cf[(k + 1) * D4GS_PROJ_BLOCK + tid] : 0.f;
+          cfloat_p B0 = (cfloat_p)(uintptr_t)a.out.blend_bases + ((size_t)s * K + k) * 16;
+          cfloat_p B1 = (cfloat_p)(uintptr_t)a.out.blend_bases + ((size_t)s * K + (two ? k + 1 : k)) * 16;
+          float r0[9], r1[9];
 #pragma unroll
-          for (int j = 0; j < 9; j++) v9[j] += c * Bk[j];
+          for (int j = 0; j < 9; j++) r0[j] = B0[j], r1[j] = B1[j];
+#pragma unroll
+          for (int j = 0; j < 9; j++) v9[j] += c0 * r0[j];
+#pragma unroll
+          for (int j = 0; j < 9; j++) v9[j] += c1 * r1[j];
         }
       } else {
         const float *B = Bs + s * K * 9;
@@ -192,6 +203,18 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
       rect = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       cnt = (x1 - x0) * (y1 - y0);
     }
+    if constexpr (XT) {  // everything the mask cannot change is stored now: only (cnt, rect) stay live across the cooperative test
+      const size_t i = (size_t)s * N + g;
+      a.out.radii[i] = radius_out;
+      *reinterpret_cast<float2 *>(a.out.means2d + i * 2) = make_float2(m2x, m2y);
+      a.out.depths[i] = dep;
+      a.out.conics[i * 3] = ca;
+      a.out.conics[i * 3 + 1] = cb;
+      a.out.conics[i * 3 + 2] = cc;
+      float4 *gp = reinterpret_cast<float4 *>(a.out.geom + i * D4GS_GEOM_STRIDE);
+      gp[0] = g0;
+      gp[1] = g1;
+    }
     }  // active
     // ---- D4GS_EXACT_TILES: which tiles of the tight rectangle does the alpha >= 1/255 ellipse reach?  The (instance, tile) pairs of
     // the wave's 64 instances are spread over its lanes (a lane-private loop over the rectangle diverges: rectangles of 1 ... 64 tiles
@@ -201,7 +224,8 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
     if constexpr (exact_tiles) {
       const int x0 = rect.x & 0xffff, x1 = rect.x >> 16, y0 = rect.y & 0xffff, y1 = rect.y >> 16;
       const int w = x1 - x0, h = y1 - y0;
-      const bool cand = cnt >= 2 && w <= 8 && h <= 8;
+      // (a 1 x n rectangle cannot lose a tile: the ellipse touches both ends of its bounding box inside the single row / column)
+      const bool cand = w >= 2 && h >= 2 && w <= 8 && h <= 8;
       const int np = cand ? cnt : 0;
       const int lane = tid & 63, wbase = tid & ~63;
       int inc = np;
@@ -261,18 +285,21 @@ __global__ void __launch_bounds__(D4GS_PROJ_BLOCK) k_project_fwd(const FwdArgs a
           for (int tx = x0; tx < x1; tx++) atomicAdd(tc + ty * a.tw + tx, 1);
       }
     }
-    if (exact_tiles) a.out.tile_masks[i] = mask;
-    a.out.radii[i] = radius_out;
-    *reinterpret_cast<float2 *>(a.out.means2d + i * 2) = make_float2(m2x, m2y);
-    a.out.depths[i] = dep;
-    a.out.conics[i * 3] = ca;
-    a.out.conics[i * 3 + 1] = cb;
-    a.out.conics[i * 3 + 2] = cc;
     a.out.tiles_touched[i] = cnt;
     *reinterpret_cast<int2 *>(a.out.tile_rects + i * 2) = rect;
-    float4 *gp = reinterpret_cast<float4 *>(a.out.geom + i * D4GS_GEOM_STRIDE);
-    gp[0] = g0;
-    gp[1] = g1;
+    if constexpr (XT) {
+      a.out.tile_masks[i] = mask;
+    } else {
+      a.out.radii[i] = radius_out;
+      *reinterpret_cast<float2 *>(a.out.means2d + i * 2) = make_float2(m2x, m2y);
+      a.out.depths[i] = dep;
+      a.out.conics[i * 3] = ca;
+      a.out.conics[i * 3 + 1] = cb;
+      a.out.conics[i * 3 + 2] = cc;
+      float4 *gp = reinterpret_cast<float4 *>(a.out.geom + i * D4GS_GEOM_STRIDE);
+      gp[0] = g0;
+      gp[1] = g1;
+    }
   }
 }
 
@@ -649,6 +676,8 @@ int d4gs_lazy_pivot_launch(const D4gsDims *d, const D4gsProjOut *out, int64_t ne
   return d4gs_check_launch("k_lazy_pivot");
 }
 
+// (256 = the CU count of the one device this library is built for - gfx950 / MI355X; the choice must not depend on a device query:
+// d4gs_query_sizes answers on GPU-less hosts too, and k_count_tiles / k_emit only need to agree with each other)
 int d4gs_chunk_per_thread(const D4gsDims *d) {
   const int64_t blocks4 = (((int64_t)d->N + 4 * COUNT_THREADS - 1) / (4 * COUNT_THREADS)) * d->S;
   return blocks4 < 256 ? 1 : 4;

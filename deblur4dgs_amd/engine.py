@@ -212,6 +212,7 @@ LAZY_AUTO_LIVE, LAZY_AUTO_KEYS = (float(x) for x in os.environ.get("D4GS_LAZY_AU
 EXACT_TILES = os.environ.get("D4GS_EXACT_TILES", "auto")
 assert EXACT_TILES in ("0", "1", "auto"), f"D4GS_EXACT_TILES={EXACT_TILES!r}"
 EXACT_TILES_FROM = float(os.environ.get("D4GS_EXACT_TILES_FROM", "3.0"))  # intersections per (sub-sample, Gaussian) instance
+EXACT_TILES_MIN_LIVE = 0.1
 _XT_ON: dict = {}  # size key -> bool: the shape's current choice (hysteresis: the test itself shortens the lists it is decided from)
 
 
@@ -225,7 +226,12 @@ def resolve_lazy(cfg, dev):
             per_inst = ((guess[0] - 4096) / 1.25 / (cfg.S * max(cfg.N, 1))) if guess else 0.0
             with _SIZE_LOCK:
                 on = _XT_ON.get(key, False)
+                live = _LIVE_FRAC.get(key)
                 on = per_inst >= (0.6 * EXACT_TILES_FROM if on else EXACT_TILES_FROM)  # on from 3 per instance, off again below 1.8
+                # ... but never for few-tile launches (their depth-segmented backward places its hand-offs by list length: shorter
+                # lists would move gradient bits between renders of one scene) and not where almost every list entry is dead
+                # anyway (cfg2 with 4x splats, 4 % live: the test costs more than the composites gain - profiles/r05_ab_exact_tiles.txt)
+                on = on and seg_state_elems(cfg) == 0 and (live is None or live >= EXACT_TILES_MIN_LIVE)
                 if len(_XT_ON) > 4 * _SIZE_GUESS_MAX:
                     _XT_ON.clear()
                 _XT_ON[key] = on
@@ -655,13 +661,23 @@ class RasterFn(torch.autograd.Function):
                    final_T=torch.empty(S, H, W, **f32))
         dims = cfg.dims()
         n_seg = seg_state_elems(cfg)  # few-tile launches: per-pixel states at depth-segment boundaries (D4gsRaster.seg_state)
-        rst["seg_state"] = torch.empty(n_seg, **f32) if n_seg > 0 else None
+        rst["seg_state"] = None
         pout = L.fill(L.ProjOut(), **{**st.proj_out, "ctab": ctab})
         ras = L.fill(L.Raster(), **rst)
         hint_used = [0]
+        seg_env = os.environ.get("D4GS_SEG")
 
         def raster(cap, max_hint):
             hint_used[0] = max_hint
+            # the library replays in depth segments only when the longest list spans more than one (max_hint > 256; D4GS_SEG=1 forces
+            # it, =0 forbids it): the boundary-state buffer - 85 MB for a 288x512 S = 1 17-channel render - is allocated only then
+            # (the forward and the backward of the render see the same pointer: ctx.rst)
+            want_seg = n_seg > 0 and seg_env != "0" and (max_hint > 256 or seg_env == "1")
+            if want_seg and rst["seg_state"] is None:
+                rst["seg_state"] = torch.empty(n_seg, **f32)
+            elif not want_seg:
+                rst["seg_state"] = None
+            ras.seg_state = L.ptr(rst["seg_state"])
             isect = L.fill(L.Isect(), **st.isect)
             isect.n_isect, isect.max_tile_count, isect.near_target = max(cap, 1), max_hint, cfg.near_target
             L.check(lib.d4gs_raster_fwd(C.byref(dims), C.byref(pout), C.byref(isect), C.byref(ras), _stream()),

@@ -84,6 +84,7 @@ def test_exact_tiles_through_the_frame_paths(fused, monkeypatch):
     for xt in (False, True, None):
         if xt is None:  # auto: the previous renders of this shape left ~4 intersections per instance -> on
             monkeypatch.setattr(engine, "EXACT_TILES", "auto")
+            monkeypatch.setattr(engine, "EXACT_TILES_FROM", 1.5)  # (the shape's measured count per instance is checked below)
         L = _leaves(sc, dev)
         r = _render(L, K, W, H, fused, exact_tiles=xt)
         ((r["blended"] * wb).sum() + (r["acc"] * wa).sum()).backward()
@@ -91,7 +92,7 @@ def test_exact_tiles_through_the_frame_paths(fused, monkeypatch):
         out[xt] = dict(blended=r["blended"], renders=r["renders"], alphas=r["alphas"], radii=r["radii"], n=r["state"].n_isect,
                        on=r["state"].cfg.exact_tiles, **{f"g_{k}": v.grad for k, v in L.items() if v is not None})
     assert out[False]["on"] is False and out[True]["on"] is True and out[None]["on"] is True
-    assert out[False]["n"] > 3 * S * N * 0.8 and out[True]["n"] < 0.93 * out[False]["n"] and out[None]["n"] == out[True]["n"]
+    assert out[False]["n"] > 2.0 * S * N and out[True]["n"] < 0.93 * out[False]["n"] and out[None]["n"] == out[True]["n"]
     for k, a in out[False].items():
         if k in ("n", "on"):
             continue

@@ -97,7 +97,7 @@ def test_pose_compose_matches_real_roma():
     near_pi = torch.arange(n) < 64
     assert bool((sign[~near_pi] > 0).all()), "quaternion sign convention differs from roma's away from the pi branch"
     err = (got * sign - want).abs().amax(-1)
-    assert float(err[~near_pi].max()) <= 2e-6
+    assert float(err[~near_pi].max()) <= 1e-5 and float(err[~near_pi].median()) <= 2e-7  # (fp32 rotmat -> quaternion of both sides)
     assert float(err[near_pi].max()) <= 5e-5  # angle within 1e-4 of pi: w = sqrt(1 + trace) / 2 ~ 5e-5 is formed from a cancelling fp32 sum
 
 
