@@ -211,8 +211,8 @@ LAZY_AUTO_LIVE, LAZY_AUTO_KEYS = (float(x) for x in os.environ.get("D4GS_LAZY_AU
 # "auto" (default) | "0" | "1"
 EXACT_TILES = os.environ.get("D4GS_EXACT_TILES", "auto")
 assert EXACT_TILES in ("0", "1", "auto"), f"D4GS_EXACT_TILES={EXACT_TILES!r}"
-EXACT_TILES_FROM = float(os.environ.get("D4GS_EXACT_TILES_FROM", "3.0"))  # intersections per (sub-sample, Gaussian) instance
-EXACT_TILES_MIN_LIVE = 0.1
+EXACT_TILES_FROM = float(os.environ.get("D4GS_EXACT_TILES_FROM", "3.5"))  # intersections per (sub-sample, Gaussian) instance
+EXACT_TILES_MIN_LIVE = 0.5
 _XT_ON: dict = {}  # size key -> bool: the shape's current choice (hysteresis: the test itself shortens the lists it is decided from)
 
 
@@ -227,10 +227,11 @@ def resolve_lazy(cfg, dev):
             with _SIZE_LOCK:
                 on = _XT_ON.get(key, False)
                 live = _LIVE_FRAC.get(key)
-                on = per_inst >= (0.6 * EXACT_TILES_FROM if on else EXACT_TILES_FROM)  # on from 3 per instance, off again below 1.8
+                on = per_inst >= (0.6 * EXACT_TILES_FROM if on else EXACT_TILES_FROM)  # on from 3.5 per instance, off again below 2.1
                 # ... but never for few-tile launches (their depth-segmented backward places its hand-offs by list length: shorter
-                # lists would move gradient bits between renders of one scene) and not where almost every list entry is dead
-                # anyway (cfg2 with 4x splats, 4 % live: the test costs more than the composites gain - profiles/r05_ab_exact_tiles.txt)
+                # lists would move gradient bits between renders of one scene) and only where most list entries are alive - the
+                # composites must gain more than the test costs the projection (profiles/r05_ab_exact_tiles.txt: cfg3, 88 % live,
+                # -1.1 %; the training shape at 720p -1.8 %; cfg5, 20 % live: +-0; cfg2 with 2x / 4x splats, 16 / 4 % live: +1.5 / +12 %)
                 on = on and seg_state_elems(cfg) == 0 and (live is None or live >= EXACT_TILES_MIN_LIVE)
                 if len(_XT_ON) > 4 * _SIZE_GUESS_MAX:
                     _XT_ON.clear()
