@@ -88,50 +88,38 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
     if (LZ == 2 && fbox[2] < 0) return;  // (block-uniform) no tile of this sub-sample needs its far part
   }
   auto taken = [&](int bk, int t) -> bool { return LZ == 1 ? bk <= piv[t] : bk > piv[t]; };
-  // CACHE (1 / 4 instances per lane): an instance's count, rectangle, depth bucket and mask stay in registers between the
-  // histogram pass and the emit pass.  STREAM (16 per lane - big tile grids, round 5): they are read again (L2 hits), since 16
-  // records per lane do not fit the register file.  Why 16: a block's histogram hands one RETURNING device-scope atomic per
-  // non-empty bin to the memory side; with 3 600 bins (720p) a 4 096-instance chunk fills a bin with only ~4.7 pairs, i.e. 14 M
-  // such atomics per cfg5 launch (~27 G/s: most of the kernel's time) - 16 384 instances per block make it 4x fewer.
-  constexpr bool CACHE = EMIT_PER_THREAD <= 4;
-  constexpr int NQ = CACHE ? EMIT_PER_THREAD : 1;
-  int cnt[NQ], rx[NQ], ry[NQ], bkq[NQ];
-  uint64_t msk[NQ];
-  // -> the instance of slot q of this lane into registers [r]; cnt[r] == 0: nothing to bin (invisible, or - LZ == 2 - no flagged tile)
-  auto load_q = [&](int q, int r) {
-    const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
-    cnt[r] = 0, msk[r] = 0;
-    if (g >= a.d.N) return;
-    const int64_t i = (int64_t)s * a.d.N + g;
-    cnt[r] = a.tiles_touched[i];
-    if (cnt[r] == 0) return;
-    const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
-    rx[r] = rc.x, ry[r] = rc.y;
-    const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-    if (LZ == 2 && (x0 > fbox[2] || x1 <= fbox[0] || y0 > fbox[3] || y1 <= fbox[1])) {
-      cnt[r] = 0;  // touches no flagged tile
-      return;
-    }
-    bkq[r] = LAZY ? d4gs_depth_bucket(a.depths[i], zlo, zhi, a.lazy.nb) : 0;
-    msk[r] = a.tile_masks ? a.tile_masks[i] : 0;
-  };
-#pragma unroll(CACHE ? EMIT_PER_THREAD : 2)
+  int cnt[EMIT_PER_THREAD], rx[EMIT_PER_THREAD], ry[EMIT_PER_THREAD], bkq[EMIT_PER_THREAD];
+  uint64_t msk[EMIT_PER_THREAD];
+#pragma unroll
   for (int q = 0; q < EMIT_PER_THREAD; q++) {
-    const int r = CACHE ? q : 0;
-    load_q(q, r);
-    if (cnt[r] == 0 || !lds) continue;
-    const int x0 = rx[r] & 0xffff, x1 = rx[r] >> 16, y0 = ry[r] & 0xffff, y1 = ry[r] >> 16;
-    if (msk[r]) {  // D4GS_EXACT_TILES: bit (ty - y0) * 8 + (tx - x0)
-      for (uint64_t m = msk[r]; m; m &= m - 1) {
-        const int b = __ffsll((long long)m) - 1, t = (y0 + (b >> 3)) * a.tw + x0 + (b & 7);
-        if (!LAZY || taken(bkq[r], t)) atomicAdd(&bins[t], 1);
-      }
-    } else {
-      for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) {
-          const int t = ty * a.tw + tx;
-          if (!LAZY || taken(bkq[r], t)) atomicAdd(&bins[t], 1);
+    const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
+    cnt[q] = 0, msk[q] = 0;
+    if (g < a.d.N) {
+      const int64_t i = (int64_t)s * a.d.N + g;
+      cnt[q] = a.tiles_touched[i];
+      if (cnt[q] > 0) {
+        const int2 rc = *reinterpret_cast<const int2 *>(a.tile_rects + i * 2);
+        rx[q] = rc.x, ry[q] = rc.y;
+        const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+        if (LZ == 2 && (x0 > fbox[2] || x1 <= fbox[0] || y0 > fbox[3] || y1 <= fbox[1])) {
+          cnt[q] = 0;  // touches no flagged tile
+          continue;
         }
+        bkq[q] = LAZY ? d4gs_depth_bucket(a.depths[i], zlo, zhi, a.lazy.nb) : 0;
+        msk[q] = a.tile_masks ? a.tile_masks[i] : 0;
+        if (lds && msk[q]) {  // D4GS_EXACT_TILES: bit (ty - y0) * 8 + (tx - x0)
+          for (uint64_t m = msk[q]; m; m &= m - 1) {
+            const int b = __ffsll((long long)m) - 1, t = (y0 + (b >> 3)) * a.tw + x0 + (b & 7);
+            if (!LAZY || taken(bkq[q], t)) atomicAdd(&bins[t], 1);
+          }
+        } else if (lds) {
+          for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++) {
+              const int t = ty * a.tw + tx;
+              if (!LAZY || taken(bkq[q], t)) atomicAdd(&bins[t], 1);
+            }
+        }
+      }
     }
   }
   if (lds) {
@@ -146,20 +134,16 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
     }
     __syncthreads();
   }
-  // fused scan: emission index base of each of the block's instances = chunk base + exclusive scan of the counts in
+  // fused scan: emission index base of each of the block's 4096 instances = chunk base + exclusive scan of the counts in
   // instance order (q-major, then lane) - exactly what k_scan_apply would have written
-  uint32_t ebase[NQ];
-  const bool fused = LZ != 2 && a.nchunks;
-  if (fused) {
+  uint32_t ebase[EMIT_PER_THREAD];
+  if (LZ != 2 && a.nchunks) {
     __shared__ int wsum[EMIT_THREADS / 64];
     int carry = a.chunk_base[s * a.nchunks + chunk];
     const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll(CACHE ? EMIT_PER_THREAD : 2)
+#pragma unroll
     for (int q = 0; q < EMIT_PER_THREAD; q++) {
-      const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
-      // (the scan runs over the instances' full counts: LZ == 2, which may zero cnt, is never fused)
-      const int c = CACHE ? cnt[q] : (g < a.d.N ? a.tiles_touched[(int64_t)s * a.d.N + g] : 0);
-      int inc = c;
+      int inc = cnt[q];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(inc, o);
@@ -174,32 +158,30 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(const EmitArgs a) {
         base += w < wave ? x : 0;
         tot += x;
       }
-      const uint32_t eb = (uint32_t)(carry + base + inc - c);
-      if (CACHE) ebase[q] = eb;
+      ebase[q] = (uint32_t)(carry + base + inc - cnt[q]);
       carry += tot;
       __syncthreads();
-      if (g < a.d.N) a.isect_offsets_out[(int64_t)s * a.d.N + g] = (int32_t)eb;  // (STREAM: read back by this lane below)
+      const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
+      if (g < a.d.N) a.isect_offsets_out[(int64_t)s * a.d.N + g] = (int32_t)ebase[q];
     }
   }
-#pragma unroll(CACHE ? EMIT_PER_THREAD : 2)
+#pragma unroll
   for (int q = 0; q < EMIT_PER_THREAD; q++) {
-    const int r = CACHE ? q : 0;
-    if (!CACHE) load_q(q, r);
-    if (cnt[r] == 0) continue;
+    if (cnt[q] == 0) continue;
     const int g = (chunk * EMIT_PER_THREAD + q) * EMIT_THREADS + tid;
     const int64_t i = (int64_t)s * a.d.N + g;
-    const int x0 = rx[r] & 0xffff, x1 = rx[r] >> 16, y0 = ry[r] & 0xffff, y1 = ry[r] >> 16;
+    const int x0 = rx[q] & 0xffff, x1 = rx[q] >> 16, y0 = ry[q] & 0xffff, y1 = ry[q] >> 16;
     const uint64_t hi = (uint64_t)__float_as_uint(a.depths[i]) << 32;
-    uint32_t e = fused ? (CACHE ? ebase[r] : (uint32_t)a.isect_offsets_out[i]) : (uint32_t)a.isect_offsets[i];
+    uint32_t e = (LZ != 2 && a.nchunks) ? ebase[q] : (uint32_t)a.isect_offsets[i];
     auto put = [&](int t) {
-      if (LAZY && !taken(bkq[r], t)) return;
+      if (LAZY && !taken(bkq[q], t)) return;
       const int slot = (LAZY || lds) ? atomicAdd(&bins[t], 1)
                                      : a.tile_offsets[tbase + t] + atomicAdd(a.tile_cursor + n_tiles_all + tbase + t, 1);
       a.keys[slot] = hi | e;
       a.gid_of_emit[e] = g;
     };
-    if (msk[r]) {  // the emission index counts the instance's BINNED tiles in ascending bit order (both lazy launches alike)
-      for (uint64_t m = msk[r]; m; m &= m - 1, e++) {
+    if (msk[q]) {  // the emission index counts the instance's BINNED tiles in ascending bit order (both lazy launches alike)
+      for (uint64_t m = msk[q]; m; m &= m - 1, e++) {
         const int b = __ffsll((long long)m) - 1;
         put((y0 + (b >> 3)) * a.tw + x0 + (b & 7));
       }
@@ -555,14 +537,6 @@ int launch_emit(const EmitArgs &e, const D4gsDims *dims, int lz, hipStream_t str
     if (lz == 0) D4GS_EMIT(1, 0);
     else if (lz == 1) D4GS_EMIT(1, 1);
     else D4GS_EMIT(1, 2);
-  } else if (pt == 16) {
-    if (lz == 0) D4GS_EMIT(16, 0);
-    else if (lz == 1) D4GS_EMIT(16, 1);
-    else D4GS_EMIT(16, 2);
-  } else if (pt == 8) {
-    if (lz == 0) D4GS_EMIT(8, 0);
-    else if (lz == 1) D4GS_EMIT(8, 1);
-    else D4GS_EMIT(8, 2);
   } else {
     if (lz == 0) D4GS_EMIT(4, 0);
     else if (lz == 1) D4GS_EMIT(4, 1);

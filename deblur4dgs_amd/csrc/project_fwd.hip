@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__rest
   int *hist2 = hist + tiles;
   const uint32_t zlo = LAZY ? ~lazy.zr[2 * s] : 0u, zhi = LAZY ? lazy.zr[2 * s + 1] : 0u;
   int touched = 0;  // this lane's share of the chunk's intersection count (fused scan: see d4gs_fused_scan)
-#pragma unroll(COUNT_PER_THREAD <= 4 ? COUNT_PER_THREAD : 2)
+#pragma unroll
   for (int q = 0; q < COUNT_PER_THREAD; q++) {
     const int g = (chunk * COUNT_PER_THREAD + q) * COUNT_THREADS + tid;
     if (g >= N) continue;
@@ -680,17 +680,9 @@ int d4gs_lazy_pivot_launch(const D4gsDims *d, const D4gsProjOut *out, int64_t ne
 // d4gs_query_sizes answers on GPU-less hosts too, and k_count_tiles / k_emit only need to agree with each other)
 int d4gs_chunk_per_thread(const D4gsDims *d) {
   const int64_t blocks4 = (((int64_t)d->N + 4 * COUNT_THREADS - 1) / (4 * COUNT_THREADS)) * d->S;
-  if (blocks4 < 256) return 1;
-  // Big tile grids (720p: 3 600 bins per sub-sample): a 4 096-instance chunk leaves only a few pairs per bin, so nearly every bin of
-  // every block costs one device-scope atomic (k_count_tiles) / one RETURNING one (k_emit) - 14 M per cfg5 launch.  16 instances
-  // per lane (k_emit re-reads its records instead of caching them) make it 4x fewer, as long as the blocks still fill the machine.
-  // D4GS_CHUNK16=0: off (A/B).
-  static const bool c16 = []() { const char *e = getenv("D4GS_CHUNK16"); return !(e && e[0] == '0'); }();
-  const int64_t tiles = (int64_t)((d->width + D4GS_TILE - 1) / D4GS_TILE) * ((d->height + D4GS_TILE - 1) / D4GS_TILE);
-  if (c16 && tiles >= 2048)
-    for (int pt = 16; pt >= 8; pt >>= 1)  // cfg5 (1 M x 16): 16; cfg3 (300 k x 8): 8
-      if ((((int64_t)d->N + pt * COUNT_THREADS - 1) / (pt * COUNT_THREADS)) * d->S >= 256) return pt;
-  return 4;
+  // (round 5, measured and dropped: 8 / 16 instances per lane on 720p grids - 4x fewer per-bin device-scope atomics - made k_emit
+  // SLOWER, cfg5 720 -> 1 139 us, cfg3 193 -> 245: its time is not those atomics; profiles/r05_ab_chunk16.txt)
+  return blocks4 < 256 ? 1 : 4;
 }
 
 // Fused scan of the per-instance intersection counts (small tile grids, i.e. every BASELINE config): k_count_tiles also
@@ -798,11 +790,7 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
                 fused_chunks ? out->scan_ws : (int *)nullptr, (const float *)out->depths, lw,                                 \
                 (const uint64_t *)((dims->flags & D4GS_EXACT_TILES) ? out->tile_masks : nullptr));                            \
   } while (0)
-    if (pt == 16 && lazy) D4GS_COUNT(16, true);
-    else if (pt == 16) D4GS_COUNT(16, false);
-    else if (pt == 8 && lazy) D4GS_COUNT(8, true);
-    else if (pt == 8) D4GS_COUNT(8, false);
-    else if (pt == 1 && lazy) D4GS_COUNT(1, true);
+    if (pt == 1 && lazy) D4GS_COUNT(1, true);
     else if (pt == 1) D4GS_COUNT(1, false);
     else if (lazy) D4GS_COUNT(4, true);
     else D4GS_COUNT(4, false);

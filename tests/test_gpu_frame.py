@@ -74,7 +74,7 @@ def test_exact_tiles_through_the_frame_paths(fused, monkeypatch):
 
     monkeypatch.setenv("D4GS_SEG", "0")
     dev = torch.device("cuda:0")
-    N, G, K_, S, W, H = 6000, 4000, 4, 3, 256, 160
+    N, G, K_, S, W, H = 9000, 6000, 4, 3, 512, 288  # (3 x 576 tiles: not a few-tile launch - `auto` never turns the test on there)
     sc = make_scene(N, G, K_, S, W, H, seed=35)
     sc["scales"] = sc["scales"] + 2.0  # exp(2) = 7.4 x: rectangles of 2 x 2 ... 4 x 4 tiles
     K = sc["K"].to(dev)
@@ -85,6 +85,7 @@ def test_exact_tiles_through_the_frame_paths(fused, monkeypatch):
         if xt is None:  # auto: the previous renders of this shape left ~4 intersections per instance -> on
             monkeypatch.setattr(engine, "EXACT_TILES", "auto")
             monkeypatch.setattr(engine, "EXACT_TILES_FROM", 1.5)  # (the shape's measured count per instance is checked below)
+            monkeypatch.setattr(engine, "EXACT_TILES_MIN_LIVE", 0.0)  # (and whatever share of its list entries is alive)
         L = _leaves(sc, dev)
         r = _render(L, K, W, H, fused, exact_tiles=xt)
         ((r["blended"] * wb).sum() + (r["acc"] * wa).sum()).backward()
