@@ -17,6 +17,31 @@ struct Policy {
 
 // `win` (optional, [P][C] bytes): for the max / min channels, the sub-sample k_blend_bwd's first-match rule would hand the gradient to
 // (-1: the mean) - the one-call backward reads it instead of re-deriving it from the S - 1 renders (frame.hip, BlendAdj)
+// sum of x[s * stride] over s < S in ascending s, the loads of eight sub-samples in flight at a time.  (Round 5: written as a plain
+// `for` the compiler kept ONE load in flight per lane - load, s_waitcnt vmcnt(0), add, branch - so a lane paid S dependent memory
+// round trips: k_blend_fwd ran at 2.0 - 2.4 TB/s; same additions in the same order, bit for bit.)
+__device__ __forceinline__ float d4gs_sum_strided(const float *__restrict__ x, int S, int64_t stride) {
+  float sum = 0.f;
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {
+    float r[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) r[u] = x[(int64_t)(s + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; u++) sum += r[u];
+  }
+  if (s + 4 <= S) {
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) r[u] = x[(int64_t)(s + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 4; u++) sum += r[u];
+    s += 4;
+  }
+  for (; s < S; s++) sum += x[(int64_t)s * stride];
+  return sum;
+}
+
 template <bool WIN>
 __global__ void __launch_bounds__(256) k_blend_fwd(int S, int64_t P, int C, const Policy policy, const float *renders,
                                                    const float *alphas, float *out, float *acc, int8_t *win,
@@ -28,8 +53,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int S, int64_t P, int C, cons
   const int64_t PC = P * C;
   if (i < PC) {
     const int c = (int)(i % C);
-    float sum = 0.f;
-    for (int s = 0; s < S; s++) sum += renders[s * PC + i];
+    const float sum = d4gs_sum_strided(renders + i, S, PC);
     const float mean = (S == 1) ? renders[i] : sum / (float)S;
     float v = mean;
     const int pol = policy.p[c];
@@ -37,32 +61,37 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int S, int64_t P, int C, cons
     // sub-sample k_blend_bwd's first-match rule hands the gradient to
     float best = 0.f;
     int w = -1;
-    if (pol == 1) {
-      for (int s = 0; s + 1 < S; s++) {
-        const float r = renders[s * PC + i];
-        v = fmaxf(v, r);
-        if (WIN && (w < 0 || r > best)) best = r, w = s;
-      }
-    } else if (pol == 2) {
-      for (int s = 0; s + 1 < S; s++) {
-        const float r = renders[s * PC + i];
-        v = fminf(v, r);
-        if (WIN && (w < 0 || r < best)) best = r, w = s;
+    if (pol != 0) {  // (eight raw values in flight at a time, then the same comparisons in the same order)
+      for (int s0 = 0; s0 + 1 < S; s0 += 8) {
+        float r[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) r[u] = (s0 + u + 1 < S) ? renders[(int64_t)(s0 + u) * PC + i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (s0 + u + 1 >= S) break;
+          if (pol == 1) {
+            v = fmaxf(v, r[u]);
+            if (WIN && (w < 0 || r[u] > best)) best = r[u], w = s0 + u;
+          } else {
+            v = fminf(v, r[u]);
+            if (WIN && (w < 0 || r[u] < best)) best = r[u], w = s0 + u;
+          }
+        }
       }
     }
     out[i] = v;
     if (WIN && pol != 0) win[i] = (int8_t)((w >= 0 && best == v) ? w : -1);
   }
   if (i < P) {
-    float sum = 0.f;
-    for (int s = 0; s < S; s++) sum += alphas[s * P + i];
+    const float sum = d4gs_sum_strided(alphas + i, S, P);
     acc[i] = (S == 1) ? alphas[i] : sum / (float)S;
   }
 }
 
 __global__ void __launch_bounds__(256) k_blend_bwd(int S, int64_t P, int C, const Policy policy, const float *renders,
                                                    const float *out, const float *v_out, const float *v_acc,
-                                                   float *v_renders, float *v_alphas, const float *add_r, const float *add_a) {
+                                                   float *v_renders, float *v_alphas, const float *add_r, const float *add_a,
+                                                   const int8_t *__restrict__ win /* k_blend_fwd's winner map, or NULL: searched here */) {
   // add_r / add_a (optional): gradients the caller holds on the per-sub-sample images themselves (losses on `exposure_imgs`,
   // flow3d/trainer.py:599-618) - summed in here, so the composite backward sees one gradient per sub-sample
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,16 +103,27 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int S, int64_t P, int C, cons
     const float inv = 1.f / (float)S;
     int winner = -1;  // -1: the mean receives the gradient
     if (pol != 0 && S > 1) {
-      const float o = out[i];
-      for (int s = 0; s + 1 < S; s++)
-        if (renders[s * PC + i] == o) {
-          winner = s;
-          break;
+      if (win) {
+        winner = win[i];  // (the one-call path: the forward left it - no reads of the S - 1 renders here)
+      } else {
+        const float o = out[i];
+        for (int s0 = 0; s0 + 1 < S && winner < 0; s0 += 8) {  // first match, eight candidates in flight at a time
+          float r[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) r[u] = (s0 + u + 1 < S) ? renders[(int64_t)(s0 + u) * PC + i] : 0.f;
+#pragma unroll
+          for (int u = 7; u >= 0; u--)
+            if (s0 + u + 1 < S && r[u] == o) winner = s0 + u;  // (descending u: the lowest matching index stays)
         }
+      }
     }
-    for (int s = 0; s < S; s++) {
-      const float v = (winner < 0) ? g * inv : (s == winner ? g : 0.f);
-      v_renders[s * PC + i] = add_r ? v + add_r[s * PC + i] : v;
+    if (add_r) {
+      for (int s = 0; s < S; s++) {
+        const float v = (winner < 0) ? g * inv : (s == winner ? g : 0.f);
+        v_renders[s * PC + i] = v + add_r[s * PC + i];
+      }
+    } else {
+      for (int s = 0; s < S; s++) v_renders[s * PC + i] = (winner < 0) ? g * inv : (s == winner ? g : 0.f);
     }
   }
   if (i < P) {
@@ -217,7 +257,7 @@ int d4gs_blend_fwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, 
 
 int d4gs_blend_bwd_add_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, const float *renders, const float *out,
                             const float *v_out, const float *v_acc, float *v_renders, float *v_alphas, const float *add_r,
-                            const float *add_a, hipStream_t stream);
+                            const float *add_a, hipStream_t stream, const int8_t *win = nullptr);
 int d4gs_blend_bwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, const float *renders, const float *out,
                         const float *v_out, const float *v_acc, float *v_renders, float *v_alphas, hipStream_t stream) {
   return d4gs_blend_bwd_add_impl(S, P, C, policy, renders, out, v_out, v_acc, v_renders, v_alphas, nullptr, nullptr, stream);
@@ -225,7 +265,7 @@ int d4gs_blend_bwd_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, 
 
 int d4gs_blend_bwd_add_impl(int32_t S, int64_t P, int32_t C, const int32_t *policy, const float *renders, const float *out,
                             const float *v_out, const float *v_acc, float *v_renders, float *v_alphas, const float *add_r,
-                            const float *add_a, hipStream_t stream) {
+                            const float *add_a, hipStream_t stream, const int8_t *win) {
   const int64_t n = P * C;
   Policy pol;
   if (C > 64 || C <= 0) {
@@ -234,7 +274,7 @@ int d4gs_blend_bwd_add_impl(int32_t S, int64_t P, int32_t C, const int32_t *poli
   }
   for (int c = 0; c < 64; c++) pol.p[c] = (c < C && policy) ? (int8_t)policy[c] : 0;
   D4GS_LAUNCH("k_blend_bwd", k_blend_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, P, C, pol, renders,
-                     out, v_out, v_acc, v_renders, v_alphas, add_r, add_a);
+                     out, v_out, v_acc, v_renders, v_alphas, add_r, add_a, win);
   return d4gs_check_launch("k_blend_bwd");
 }
 

@@ -17,7 +17,7 @@ int d4gs_blend_fwd_impl(int32_t, int64_t, int32_t, const int32_t *, const float 
                         hipStream_t, const int64_t *n_isect = nullptr, int64_t *counts_pinned = nullptr);
 int d4gs_copy_counts_impl(const int64_t *n_isect, int64_t *host_pinned, hipStream_t stream);
 int d4gs_blend_bwd_add_impl(int32_t, int64_t, int32_t, const int32_t *, const float *, const float *, const float *,
-                            const float *, float *, float *, const float *, const float *, hipStream_t);
+                            const float *, float *, float *, const float *, const float *, hipStream_t, const int8_t *win = nullptr);
 
 namespace {
 
@@ -142,7 +142,7 @@ int d4gs_forward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO *
   if (io->blended) {
     const int nch = dims->D + (dims->depth_mode != D4GS_DEPTH_NONE ? 1 : 0);
     rc = d4gs_blend_fwd_impl(dims->S, (int64_t)dims->width * dims->height, nch, io->policy, io->renders, io->alphas, io->blended,
-                             io->acc, dims->D <= 5 ? b.blend_win : nullptr, stream,  // (the map is for the folded adjoint: narrow renders)
+                             io->acc, b.blend_win, stream,  // (the winner map: read by the folded adjoint or by k_blend_bwd)
                              io->n_isect, io->counts_pinned);
   } else if (io->counts_pinned) {
     rc = d4gs_copy_counts_impl(io->n_isect, io->counts_pinned, stream);
@@ -184,7 +184,8 @@ int d4gs_backward(const D4gsDims *dims, const D4gsProjIn *in, const D4gsFrameIO 
     const int nch = dims->D + (dims->depth_mode != D4GS_DEPTH_NONE ? 1 : 0);
     // (gradients the caller holds on the sub-sample images themselves are summed in by the same kernel)
     if ((rc = d4gs_blend_bwd_add_impl(dims->S, (int64_t)dims->width * dims->height, nch, io->policy, io->renders, io->blended,
-                                      g->v_blended, g->v_acc, b.v_renders, b.v_alphas, g->v_renders, g->v_alphas, stream)))
+                                      g->v_blended, g->v_acc, b.v_renders, b.v_alphas, g->v_renders, g->v_alphas, stream,
+                                      b.blend_win)))
       return rc;
     v_renders = b.v_renders, v_alphas = b.v_alphas;
   }

@@ -101,13 +101,30 @@ k_project_fwd(const FwdArgs a) {
     if (raw) opac = 1.f / (1.f + expf(-opac));
     a.out.opac_act[g] = opac;
     const int D = d.D, DP = (D + 3) & ~3;
-    for (int ch = 0; ch < DP; ch++) {
+    // the colour table row: the channels that may need the sigmoid one by one (as before: the exp expansion stays single), the rest
+    // 16 bytes at a time - a dword per channel and lane is DP stores of 64 scattered 4-byte pieces per wave: with 16 channels
+    // k_project_fwd took 110 us against 64 with 3 (round 5)
+    const int nsig4 = (d.flags & D4GS_RAW_COLORS) ? min((d.n_sigmoid + 3) & ~3, DP) : 0;
+    for (int ch = 0; ch < nsig4; ch++) {
       float v = 0.f;
       if (ch < D) {
         v = a.in.colors[(size_t)g * D + ch];
-        if ((d.flags & D4GS_RAW_COLORS) && ch < d.n_sigmoid) v = 1.f / (1.f + expf(-v));
+        if (ch < d.n_sigmoid) v = 1.f / (1.f + expf(-v));
       }
       a.out.ctab[(size_t)g * DP + ch] = v;
+    }
+    const bool vec_in = (D & 3) == 0 && (((uintptr_t)a.in.colors) & 15) == 0;
+    for (int ch = nsig4; ch < DP; ch += 4) {
+      float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec_in) {
+        v4 = *reinterpret_cast<const float4 *>(a.in.colors + (size_t)g * D + ch);
+      } else {
+        if (ch < D) v4.x = a.in.colors[(size_t)g * D + ch];
+        if (ch + 1 < D) v4.y = a.in.colors[(size_t)g * D + ch + 1];
+        if (ch + 2 < D) v4.z = a.in.colors[(size_t)g * D + ch + 2];
+        if (ch + 3 < D) v4.w = a.in.colors[(size_t)g * D + ch + 3];
+      }
+      *reinterpret_cast<float4 *>(a.out.ctab + (size_t)g * DP + ch) = v4;
     }
   }
   if (active) {
