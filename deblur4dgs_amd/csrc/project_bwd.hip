@@ -662,22 +662,32 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
 // launch of the same kernel adds the RCH chunk sums.  (Round 2 had a wave stride over the blocks of one output: 4-byte
 // reads n floats apart - 30 us once the 64-Gaussian blocks made 4x as many partials.)
 constexpr int RCH = 64;
+// rows [b0, b1) of `x` (row length n), column o, summed into four interleaved accumulators ((a0 + a1) + (a2 + a3) at the end): the one
+// order both reduction passes use.  Sixteen rows are LOADED before they are added (round 5: the `#pragma unroll 4` loop still waited
+// for each group of four - a lane of the one-block k_finish paid 16 dependent round trips for its 64 chunk sums); same additions, same order.
+__device__ __forceinline__ float d4gs_sum_rows(const float *__restrict__ x, int b0, int b1, int n, int o) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = b0;
+  for (; b + 15 < b1; b += 16) {
+    float r[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) r[u] = x[(size_t)(b + u) * n + o];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) a0 += r[u], a1 += r[u + 1], a2 += r[u + 2], a3 += r[u + 3];
+  }
+  for (; b + 3 < b1; b += 4) {
+    const float r0 = x[(size_t)b * n + o], r1 = x[(size_t)(b + 1) * n + o], r2 = x[(size_t)(b + 2) * n + o], r3 = x[(size_t)(b + 3) * n + o];
+    a0 += r0, a1 += r1, a2 += r2, a3 += r3;
+  }
+  for (; b < b1; b++) a0 += x[(size_t)b * n + o];
+  return (a0 + a1) + (a2 + a3);
+}
 __global__ void __launch_bounds__(256) k_reduce_partials(const float *partials, int n_blocks, int n, float *out) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= n) return;
   const int per = (n_blocks + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(b0 + per, n_blocks);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int b = b0;
-#pragma unroll 4  // (sixteen rows in flight; the order of the additions is unchanged)
-  for (; b + 3 < b1; b += 4) {
-    a0 += partials[(size_t)b * n + o];
-    a1 += partials[(size_t)(b + 1) * n + o];
-    a2 += partials[(size_t)(b + 2) * n + o];
-    a3 += partials[(size_t)(b + 3) * n + o];
-  }
-  for (; b < b1; b++) a0 += partials[(size_t)b * n + o];
-  out[(size_t)blockIdx.y * n + o] = (a0 + a1) + (a2 + a3);
+  out[(size_t)blockIdx.y * n + o] = d4gs_sum_rows(partials, b0, b1, n, o);
 }
 
 // scatter the reduced shared gradients: v_Bs -> rots / transls / times ; camera deltas ; viewmat.
@@ -692,19 +702,7 @@ __global__ void __launch_bounds__(1024) k_finish(const BwdArgs a, const float *r
   const float *red = red_in;
   if (n_in > 0) {
     const int n = a.n_shared;
-    for (int o = threadIdx.x; o < n; o += blockDim.x) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int b = 0;
-#pragma unroll 4
-      for (; b + 3 < n_in; b += 4) {
-        a0 += red_in[(size_t)b * n + o];
-        a1 += red_in[(size_t)(b + 1) * n + o];
-        a2 += red_in[(size_t)(b + 2) * n + o];
-        a3 += red_in[(size_t)(b + 3) * n + o];
-      }
-      for (; b < n_in; b++) a0 += red_in[(size_t)b * n + o];
-      sred[o] = (a0 + a1) + (a2 + a3);
-    }
+    for (int o = threadIdx.x; o < n; o += blockDim.x) sred[o] = d4gs_sum_rows(red_in, 0, n_in, n, o);
     __syncthreads();
     red = sred;
   }
