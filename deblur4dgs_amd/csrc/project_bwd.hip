@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   const bool dyn = G > 0;
   const int K = dyn ? d.K : 0;
   const int KP = K | 1;
-  const int nk = K * 9, nk4 = (nk + 3) & ~3, nop = nk + 13;
+  const int nk = K * 9, nop = nk + 13;
   const bool shared = dyn || a.in.RTs;
   const int no = nk + 12;
   constexpr int NSG = SLOTS / SL;  // sub-groups per block (SL = 4: one, the round-3 mapping)
