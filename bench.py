@@ -77,7 +77,8 @@ def parse():
     ap.add_argument("--mesh", default=None, metavar="VxE", help="with --shard mesh: V views x E-way exposure sharding, V * E == --gpus")
     ap.add_argument("--graph-timeout", type=float, default=90.0,
                     help="N > 1: seconds each phase after the first (eager) measurement may take - the HIP-graph capture / replays with RCCL "
-                         "collectives inside, the secondary measurements - before a watchdog prints the line measured so far and exits 0")
+                         "collectives inside, the secondary measurements - before a watchdog prints the line measured so far and exits 0 "
+                         "(the eager measurement itself gets 3x this; if IT hangs there is no line and the exit code is 3)")
     ap.add_argument("--channels", type=int, default=None, choices=[3, 16],
                     help="colour channels before depth: 3 = RGB+ED (headline), 16 = the reference's dynamic-training "
                          "shape (rgb + mask + 4x3 track channels + depth = 17, scene_model.py:233-296; default of "
@@ -371,16 +372,16 @@ class Watchdog:
         t = threading.Thread(target=self._run, daemon=True)
         t.start()
 
-    def kick(self, phase: str, out=None):
-        """A phase starts: (re)arm the deadline; `out` replaces the line a firing watchdog prints."""
+    def kick(self, phase: str, out=None, scale: float = 1.0):
+        """A phase starts: (re)arm the deadline (`scale` x the timeout); `out` replaces the line a firing watchdog prints."""
         import faulthandler
 
         with self._lock:
             self.phase = phase
             if out is not None:
                 self.out = json.loads(json.dumps(out))  # a private copy: the main thread keeps editing its own
-            self.deadline = time.monotonic() + self.timeout
-        faulthandler.dump_traceback_later(self.timeout + 30.0, exit=True)
+            self.deadline = time.monotonic() + scale * self.timeout
+        faulthandler.dump_traceback_later(scale * self.timeout + 30.0, exit=True)
 
     def done(self):
         import faulthandler
@@ -401,9 +402,10 @@ class Watchdog:
                                                               "capture?); this is the line measured before it (eager step)")
                     out["watchdog_fired_in"] = phase
                     os.write(1, (json.dumps(out) + "\n").encode())
-                sys.stderr.write(f"[bench.py rank {self.rank}] watchdog: phase '{phase}' timed out; leaving with the line measured so far\n")
+                sys.stderr.write(f"[bench.py rank {self.rank}] watchdog: phase '{phase}' timed out; leaving with "
+                                 + ("the line measured so far\n" if out is not None else "NO line: nothing had been measured yet\n"))
                 sys.stderr.flush()
-                os._exit(0)
+                os._exit(0 if out is not None else 3)
 
 
 def resolve_shard(args, world):
@@ -946,10 +948,14 @@ def main():
     # ---- the measurements.  N = 1: one (eager by default).  N > 1: the EAGER primary step first - its line is kept - then, under the
     # watchdog, the HIP-graph version of it and the secondary shardings; one JSON line whatever happens after the first measurement.
     first_graph = want_graph and not eager_first
+    wd = Watchdog(rank, args.graph_timeout) if world > 1 else None
+    if wd:  # nothing to print if THIS hangs (communicator bring-up, the first collective): leave with exit code 3 instead of waiting
+        wd.kick("eager primary step (communicator bring-up, first collectives)", scale=3.0)  # for RCCL's 600 s watchdog / the driver's clock
+        if dry and os.environ.get("D4GS_BENCH_INJECT_HANG") == "eager" and rank == world - 1:
+            time.sleep(1e6)  # tests/test_parallel_gloo.py: a rank that never joins the first collective
     res = measure(primary_mode, primary_mesh, args.steps, args.warmup, prof_ok and not first_graph, first_graph)
     out = line_of(res, primary_mode, primary_mesh)
     if world > 1:
-        wd = Watchdog(rank, args.graph_timeout)
         graph_ok = False
         if eager_first:
             out["config"]["launch"] = "eager step (the HIP-graph attempt had not finished)"

@@ -86,7 +86,10 @@ __device__ __forceinline__ void rotmat_adj_to_quat(const float *q, const float *
 // address, constant address space: s_load_dwordx8 + dword per basis) and the values are SGPR operands of the multiply-adds: no LDS
 // traffic, no transient VGPRs (128 VGPRs + a 24-byte scratch frame -> 122, none).  Row stride 16 floats.  Measured (A/B build, same
 // run): cfg2 119.5 -> 112.5 us, cfg3 118.5 -> 112.6, refdefault (K = 20) 128 -> 118, cfg5 (K = 12) 967 -> 736 (profiles/r05_ab_bases_table.txt).
+// contract(off): the same two products and one sum as k_project_fwd's preblend_bases (and the reference's lerp), bit for bit - the table a
+// caller without `blend_bases` gets here must be the one the forward rendered with (tests/test_gpu_exposure.py).
 __global__ void __launch_bounds__(256) k_bases_table(const D4gsDims d, const float *times, const float *rots, const float *transls, float *btab) {
+#pragma clang fp contract(off)
   const int s = blockIdx.x, K = d.K, T = d.T;
   const float t = times[s];
   const float ff = fminf(fmaxf(floorf(t), 0.f), (float)(T - 1));

@@ -28,6 +28,7 @@ struct FwdArgs {
 
 // time-blended bases: Bs[s][k][0:3] = transl, [3:9] = 6-D rotation   (params.py:152-177; w uses the clamped floor)
 __device__ __forceinline__ void preblend_bases(const FwdArgs &a, float *Bs) {
+#pragma clang fp contract(off)  // two products, one sum: torch's lerp and k_bases_table's, bit for bit
   const int K = a.d.K, T = a.d.T;
   for (int idx = threadIdx.x; idx < a.d.S * K * 9; idx += blockDim.x) {
     int s = idx / (K * 9), r = idx - s * K * 9, k = r / 9, j = r - k * 9;

@@ -210,3 +210,31 @@ def test_blend_kernels_match_the_reference_blend(S, H, W, Cn):
         assert float((got.detach().cpu().double() - want.detach()).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), name
     # the routing is exact: a max / min channel's gradient lands on ONE sub-sample (or is spread as the mean's)
     assert torch.equal(r.grad.cpu() != 0, r_ref.grad != 0)
+
+
+def test_backward_builds_its_own_bases_table_when_the_caller_gives_none():
+    """D4gsProjOut.blend_bases is optional (include/d4gs.h): a v304 caller leaves it NULL and d4gs_project_bwd blends
+    the table behind its partials.  Same bits either way."""
+    from deblur4dgs_amd.exposure import render_exposure
+
+    N, G, K, S, W, H = 1300, 800, 6, 4, 80, 48
+    sc = make_scene(N, G, K, S, W, H, seed=77, dtype=torch.float32, cam_jitter=0.01)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(H, W, 4, generator=g).to(dev)
+    grads = []
+    for drop in (False, True):
+        L = {k: sc[k].to(dev).clone().requires_grad_() for k in ("means", "quats", "scales", "opacities", "colors", "rots",
+                                                                 "transls", "times", "RTs")}
+        coefs = sc["motion_coefs"].to(dev).clone().requires_grad_()
+        res = render_exposure(L["means"], L["quats"], L["scales"], L["opacities"], L["colors"], 3, coefs, L["rots"], L["transls"],
+                              L["times"], L["RTs"], sc["viewmat"].to(dev), sc["K"].to(dev), W, H, return_depth=True)
+        if drop:
+            assert res["state"].proj_out["blend_bases"] is not None
+            res["state"].proj_out["blend_bases"] = None
+        (res["blended"] * w).sum().backward()
+        torch.cuda.synchronize()
+        grads.append({**{k: v.grad.clone() for k, v in L.items()}, "motion_coefs": coefs.grad.clone()})
+    for k in grads[0]:
+        assert grads[0][k].abs().max() > 0, k
+        assert torch.equal(grads[0][k], grads[1][k]), k

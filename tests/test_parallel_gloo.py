@@ -382,3 +382,23 @@ def test_bench_prints_the_eager_line_when_the_graph_phase_hangs():
     assert "WATCHDOG" in d["config"]["launch"] and "HIP-graph capture" in d["watchdog_fired_in"]
     assert d["scaling"] == "strong" and "views_weak_scaling" not in d  # nothing after the hung phase ran
     assert "watchdog" in err
+
+
+def test_bench_leaves_with_exit_code_3_when_the_first_collective_hangs():
+    """Nothing has been measured when the EAGER step hangs (communicator bring-up, the first collective): no line can be printed, but
+    every rank must still leave on its own - exit code 3, the phase named on stderr - instead of sitting in the collective until the
+    backend's own time-out (600 s for RCCL) or the driver's clock."""
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--dry-run", "--graph-timeout", "4"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root, env={**os.environ, "D4GS_BENCH_INJECT_HANG": "eager"})
+    assert time.time() - t0 < 120
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")], r.stdout  # no half-measured line
+    assert "NO line" in r.stderr and "eager primary step" in r.stderr
