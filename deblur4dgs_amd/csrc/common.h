@@ -478,6 +478,35 @@ __device__ __forceinline__ void rowsum_all(float (&z)[NR]) {
 }
 // Sum v[0..R) over the wave and store the R totals to arr[at .. at + R) (LDS); arr[at + R] must be a writable pad
 // slot.  `arr` is the __shared__ array itself and `at` an int offset so that the address math stays 32-bit.
+// Three folded registers (R = 9 / 10: the composite backward's rows, k_project_bwd's per-basis sums) share ONE 16-lane ladder
+// (round 5): after the first quad step the odd lanes of z0 take z1's pair sums, after the second lane 3 of every quad takes z2's
+// quad sum, and the remaining two steps rotate by whole quads (row_ror:4 / :8 keep lane & 3) - 10 DPP / select instructions
+// instead of 13, one LDS store instead of three.  Slot lane & 3 of every row then holds: 0 -> z0, 1 -> z1, 3 -> z2 (whose rows the
+// row_bcast steps then combine in lanes 12..15).
+#ifndef D4GS_PACKED_LADDER
+#define D4GS_PACKED_LADDER 1
+#endif
+#define D4GS_C7 "row_ror:4 row_mask:0xf bank_mask:0xf"
+#define D4GS_C8 "row_ror:8 row_mask:0xf bank_mask:0xf"
+#define D4GS_C5S "row_bcast:15 row_mask:0xa bank_mask:0x8"
+#define D4GS_C6S "row_bcast:31 row_mask:0xc bank_mask:0x8"
+template <bool SINGLE /* z2 is one value (rows 0..3 -> row 3) instead of two (rows 0,1 -> 1; 2,3 -> 3) */>
+__device__ __forceinline__ float rowsum3_packed(float a, float b, float c) {
+  const uint64_t odd = 0xaaaaaaaaaaaaaaaaull, l3 = 0x8888888888888888ull;
+  if constexpr (SINGLE)
+    asm volatile("s_nop 1\n\t" D4GS_R3(D4GS_C1) "v_cndmask_b32_e64 %0, %0, %1, %3\n\ts_nop 0\n\t" D4GS_DA(2, D4GS_C2) D4GS_DA(0, D4GS_C2)
+                 "v_cndmask_b32_e64 %0, %0, %2, %4\n\ts_nop 1\n\t" D4GS_DA(0, D4GS_C7) "s_nop 1\n\t" D4GS_DA(0, D4GS_C8)
+                 "s_nop 1\n\t" D4GS_DA(0, D4GS_C5S) "s_nop 1\n\t" D4GS_DA(0, D4GS_C6S)
+                 : "+v"(a), "+v"(b), "+v"(c)
+                 : "s"(odd), "s"(l3));
+  else
+    asm volatile("s_nop 1\n\t" D4GS_R3(D4GS_C1) "v_cndmask_b32_e64 %0, %0, %1, %3\n\ts_nop 0\n\t" D4GS_DA(2, D4GS_C2) D4GS_DA(0, D4GS_C2)
+                 "v_cndmask_b32_e64 %0, %0, %2, %4\n\ts_nop 1\n\t" D4GS_DA(0, D4GS_C7) "s_nop 1\n\t" D4GS_DA(0, D4GS_C8)
+                 "s_nop 1\n\t" D4GS_DA(0, D4GS_C5S)
+                 : "+v"(a), "+v"(b), "+v"(c)
+                 : "s"(odd), "s"(l3));
+  return a;
+}
 template <int R>
 __device__ __forceinline__ void wave_sum_store(float (&v)[R], float *arr, int at, int lane) {
   constexpr int n4 = R / 4, rem = R % 4, n2 = rem / 2, n1 = rem % 2, NR = n4 + n2 + n1;
@@ -487,6 +516,18 @@ __device__ __forceinline__ void wave_sum_store(float (&v)[R], float *arr, int at
     z[g] = swap16_add(swap32_add(v[4 * g], v[4 * g + 1]), swap32_add(v[4 * g + 2], v[4 * g + 3]));
   if constexpr (n2) z[n4] = swap32_add(v[4 * n4], v[4 * n4 + 1]);
   if constexpr (n1) z[NR - 1] = v[R - 1];
+  if constexpr (D4GS_PACKED_LADDER && n4 == 2 && n2 + n1 == 1) {
+    const float q = rowsum3_packed<n1 == 1>(z[0], z[1], z[2]);
+    const int r = lane >> 4, k = lane & 15;
+    const int o4 = ((r & 1) << 1) | (r >> 1);  // rows hold (v0, v2, v1, v3)
+    // (z2's totals are taken from lane 15 of the row: bank_mask 0x8 = lanes 12..15 of a row are the ones the row_bcast steps write)
+    const bool w = k < 2 || (k == 15 && (n1 ? r == 3 : (r & 1)));
+    const int off = k < 2 ? 4 * k + o4 : 8 + (n1 ? 0 : (r >> 1));
+    int ats = at;  // (wave-uniform at every call site; pinned to an SGPR so that the row offset is not folded into a 64-bit VALU mad)
+    asm volatile("" : "+s"(ats));
+    if (w) arr[ats + off] = q;
+    return;
+  }
   rowsum_all(z);
   if constexpr (n2) bcast15(z[n4]);
   if constexpr (n1) bcast15_31(z[NR - 1]);

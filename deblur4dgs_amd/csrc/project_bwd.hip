@@ -19,6 +19,11 @@
 // (Round 2: one lane per Gaussian looping over S with 27 accumulators at 253 VGPRs, 2 waves / SIMD, 4 688 waves for
 // 2 048 wave slots on cfg2.)  Block partials of the shared gradients are summed over blocks by k_reduce_partials in a
 // fixed order and scattered to rots / transls / times by k_finish.
+// (wave_sum_store's packed ladder - common.h - is for the composite backward; here its four s_nop-separated steps sit on the critical
+// path of a 4-wave kernel: measured 106.7 -> 108.7 us on cfg2, so this file keeps the three-register ladder)
+#ifndef D4GS_PACKED_LADDER
+#define D4GS_PACKED_LADDER 0
+#endif
 #include "common.h"
 
 namespace {
