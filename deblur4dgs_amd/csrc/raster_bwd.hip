@@ -277,6 +277,9 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
       for (int r = 0; r < R; r++) dst[r] = 0.f;
     }
 
+  // va - (the suffix sum of fac * d over the contributors behind the current one), kept as ONE running value: a multiply-add per hit
+  // instead of a subtraction and a multiply-add
+  float vab = va - bsum;
   for (int bh = hi; bh >= start; bh -= NB) {
     __syncthreads();
     int emit = -1;
@@ -362,8 +365,8 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
           myfac[lane * FS + nh] = fac;
           if (lane == 0) myhit[nh] = j;
         }
-        const float v_alpha = __builtin_fmaf(T, d, ra * (va - bsum));
-        bsum = __builtin_fmaf(fac, d, bsum);
+        const float v_alpha = __builtin_fmaf(T, d, ra * vab);
+        vab = __builtin_fmaf(-fac, d, vab);
         const bool ok = valid && (ov <= 0.999f);
         const float vs = ok ? -ov * v_alpha : 0.f;
         // raw pixel sums only; the per-splat linear map (conic, ln2, 1/2, 1/opacity) is applied once at write-out
