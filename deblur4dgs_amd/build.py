@@ -27,7 +27,9 @@ VARIANT_SOURCES = ("raster_fwd.hip", "raster_bwd.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # per-file extras.  project_bwd: the SLP vectorizer turns the adjoint chain into v_pk_* math, which is not faster on gfx950 (4.5
 # cycles for two operations against 2.5 for one) and parks ~40 duplicated operands in VGPR pairs: 256 + 30 registers instead of 128
-FILE_FLAGS = {"project_bwd.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"project_bwd.hip": ["-fno-slp-vectorize"],
+              # raster_fwd: the four unrolled composite steps per list read pair up into v_pk_* math behind a dozen v_mov shuffles
+              "raster_fwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _cuid(src: str) -> str:

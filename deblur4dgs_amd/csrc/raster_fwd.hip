@@ -89,6 +89,16 @@ template <> struct BoxT<false> {
   static __device__ __forceinline__ float4 unpack(float4 p) { return p; }
 };
 
+// 16 x byte B of a dword in one instruction (SDWA byte select on the shift's operand; the compiler emits v_bfe_u32 + v_lshlrev_b32)
+template <int B>
+__device__ __forceinline__ int d4gs_byte_x16(uint32_t w) {
+  int r;
+  if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(4u), "v"(w));
+  if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(4u), "v"(w));
+  if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(4u), "v"(w));
+  if constexpr (B == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(4u), "v"(w));
+  return r;
+}
 template <int D, bool DEPTH, bool SEG = false>
 __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 #pragma clang fp contract(off)
@@ -101,7 +111,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   __shared__ float4 sg1[FB];
   __shared__ typename BoxT<(DV <= 1)>::type sbox[FB];  // tight box in tile-local pixels
   __shared__ float4 scol[FB * DV];
-  __shared__ unsigned char slist[4 * 4 * FB];  // [wave][row][position]
+  __shared__ __attribute__((aligned(16))) unsigned char slist[4 * 4 * FB];  // [wave][row][position]
 
   D4GS_TCLK(_t0)
 #ifdef D4GS_TRACE
@@ -193,6 +203,14 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     const int nb = min(FB, end - b);
     // ---- per-row lists of this wave's quadrant ----
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // wave-uniform list lengths
+    // The wave's four lists start out as zeros (one 16-byte store per lane and batch): the composite loop reads list bytes past a
+    // row's count (no divergent branch in it) and takes them as they are - staged splat 0 exists in every batch, a stale index could
+    // point at a never-staged record (NaN * 0) - instead of replacing them lane by lane in every step.
+    constexpr bool NARROW = DV == 1;  // one colour record: the four-steps-per-read loop below; wide records keep the one-byte loop (regs)
+    if constexpr (NARROW) {
+      if (lane * 16 < 4 * FB) reinterpret_cast<uint4 *>(wlist)[lane] = make_uint4(0u, 0u, 0u, 0u);
+      __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int k = 0; k < FB / 64; k++) {
       const int jj = k * 64 + lane;
@@ -216,28 +234,28 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     D4GS_TADD(_tl, _tb, _tc0)
     const int cnt = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
     const int imax = max(max(c0, c1), max(c2, c3));
-    int lastj = -1;
-    for (int i0 = 0; i0 < imax; i0 += 16) {  // every 16 iterations: is the whole wave saturated?
-     const int i1 = min(i0 + 16, imax);
-     for (int i = i0; i < i1; i++) {
-      const bool act = i < cnt;
-      // the byte is read unconditionally (no divergent branch in the loop; i < FB stays inside the row's list) and
-      // replaced by staged splat 0 past the row's count: a stale index could point at a never-staged record (NaN * 0)
-      const int jr = (int)mylist[i];
-      const int j = act ? jr : 0;
-      const float4 g0 = sg0[j], g1 = sg1[j];
+    int last16 = -1;  // 16 x the slot of the batch's last contributor to this pixel
+    unsigned long long donem = __builtin_amdgcn_ballot_w64(done);  // the saturated pixels of this wave as a lane mask (all 64 lanes are active here)
+    // One composite step of this lane's row: staged splat `jr` (ignored past the row's count).
+    auto step = [&](const unsigned long long actm, const int j16 /* 16 x the staged splat's slot: the byte offset of its records */) {
+      const float4 g0 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sg0) + j16);
+      const float4 g1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sg1) + j16);
       const float dx = g0.x - pxf, dy = g0.y - pyf;
       const float sigma = splat_sigma2(g1, dx, dy);  // sigma * log2(e)
       const float alpha = fminf(0.999f, g0.z * __builtin_amdgcn_exp2f(-sigma));
-      bool valid = act && !done && (sigma >= 0.f) && (alpha >= (1.f / 255.f));
       const float nT = T * (1.f - alpha);
-      const bool sat = nT <= 1e-4f;  // one compare feeds both masks
-      done = done || (valid && sat);
-      valid = valid && !sat;
+      // The lane masks are handled as what they are - 64-bit scalars: ONE compare against the saturation threshold feeds both the
+      // composite (as it is) and `done` (its complement, a scalar and-not).  Written with bools the compiler issues that compare twice
+      // (v_cmp_ge + v_cmp_nge / v_cmp_lt + v_cmp_nlt).
+      // (one ballot per compare: the ballot of a conjunction is lowered through a VGPR - v_cndmask + v_cmp_ne)
+      const unsigned long long vm = actm & __builtin_amdgcn_ballot_w64(sigma >= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= (1.f / 255.f)) & ~donem;
+      const unsigned long long mm = __builtin_amdgcn_ballot_w64(nT > 1e-4f);  // (hip's __ballot goes through an int: v_cndmask + v_cmp)
+      donem |= vm & ~mm;
+      const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm & mm);
       const float vis = valid ? alpha * T : 0.f;
 #pragma unroll
       for (int v = 0; v < DV; v++) {
-        const float4 c4 = scol[j * DV + v];
+        const float4 c4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(scol) + j16 * DV + 16 * v);
         if (v * 4 < D) acc[v * 4] = __builtin_fmaf(c4.x, vis, acc[v * 4]);
         if (v * 4 + 1 < D) acc[v * 4 + 1] = __builtin_fmaf(c4.y, vis, acc[v * 4 + 1]);
         if (v * 4 + 2 < D) acc[v * 4 + 2] = __builtin_fmaf(c4.z, vis, acc[v * 4 + 2]);
@@ -245,12 +263,64 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       }
       if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
       T = valid ? nT : T;
-      lastj = valid ? j : lastj;
-     }
-     if (__all(done)) break;
+      last16 = valid ? j16 : last16;
+    };
+#ifndef D4GS_FWD_LIST4
+#define D4GS_FWD_LIST4 1
+#endif
+    if constexpr (D4GS_FWD_LIST4 && NARROW) {
+      // Four list positions per LDS read (the rows' lists start on 4-byte boundaries, FB is a multiple of 4): one address add and one read
+      // per four steps; up to three steps past the longest list run with no row active.  Measured against the one-byte loop (cfg2,
+      // profiles/r05_ab_fwd_list4.txt): 267 -> 238 us; with wide records the four unrolled steps cost the occupancy (17 channels:
+      // 80 -> 126 VGPRs), so those keep the loop below.
+      for (int i0 = 0; i0 < imax; i0 += 16) {  // every 16 iterations: is the whole wave saturated?
+        const int i1 = min(i0 + 16, imax);
+        for (int i = i0; i < i1; i += 4) {
+          const uint32_t w4 = *reinterpret_cast<const uint32_t *>(mylist + i);
+          step(__builtin_amdgcn_ballot_w64(i < cnt), d4gs_byte_x16<0>(w4));
+          step(__builtin_amdgcn_ballot_w64(i + 1 < cnt), d4gs_byte_x16<1>(w4));
+          step(__builtin_amdgcn_ballot_w64(i + 2 < cnt), d4gs_byte_x16<2>(w4));
+          step(__builtin_amdgcn_ballot_w64(i + 3 < cnt), d4gs_byte_x16<3>(w4));
+        }
+        if (donem == ~0ull) break;
+      }
+      done = __builtin_amdgcn_inverse_ballot_w64(donem);
+    } else {
+      for (int i0 = 0; i0 < imax; i0 += 16) {
+        const int i1 = min(i0 + 16, imax);
+        for (int i = i0; i < i1; i++) {
+          const bool act = i < cnt;
+          // the byte is read unconditionally (no divergent branch in the loop; i < FB stays inside the row's list) and
+          // replaced by staged splat 0 past the row's count: a stale index could point at a never-staged record (NaN * 0)
+          const int jr = (int)mylist[i];
+          const int j = act ? jr : 0;
+          const float4 g0 = sg0[j], g1 = sg1[j];
+          const float dx = g0.x - pxf, dy = g0.y - pyf;
+          const float sigma = splat_sigma2(g1, dx, dy);  // sigma * log2(e)
+          const float alpha = fminf(0.999f, g0.z * __builtin_amdgcn_exp2f(-sigma));
+          bool valid = act && !done && (sigma >= 0.f) && (alpha >= (1.f / 255.f));
+          const float nT = T * (1.f - alpha);
+          const bool sat = nT <= 1e-4f;
+          done = done || (valid && sat);
+          valid = valid && !sat;
+          const float vis = valid ? alpha * T : 0.f;
+#pragma unroll
+          for (int v = 0; v < DV; v++) {
+            const float4 c4 = scol[j * DV + v];
+            if (v * 4 < D) acc[v * 4] = __builtin_fmaf(c4.x, vis, acc[v * 4]);
+            if (v * 4 + 1 < D) acc[v * 4 + 1] = __builtin_fmaf(c4.y, vis, acc[v * 4 + 1]);
+            if (v * 4 + 2 < D) acc[v * 4 + 2] = __builtin_fmaf(c4.z, vis, acc[v * 4 + 2]);
+            if (v * 4 + 3 < D) acc[v * 4 + 3] = __builtin_fmaf(c4.w, vis, acc[v * 4 + 3]);
+          }
+          if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
+          T = valid ? nT : T;
+          last16 = valid ? 16 * j : last16;
+        }
+        if (__all(done)) break;
+      }
     }
-    last = lastj >= 0 ? b + lastj : last;  // list index of the batch's last contributor, formed once per batch
-    has_last = has_last || lastj >= 0;
+    last = last16 >= 0 ? b + (last16 >> 4) : last;  // list index of the batch's last contributor, formed once per batch
+    has_last = has_last || last16 >= 0;
     D4GS_TCLK(_tc1)
     D4GS_TADD(_tc, _tc0, _tc1)
 #ifdef D4GS_TRACE
