@@ -107,6 +107,15 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   constexpr int DV = DP / 4;
   constexpr int FB = (DV > 2 || (SEG && D4GS_SEG_UNIT < 256)) ? 128 : 256;  // splats per batch (indices fit one byte); wide colour records: smaller
                                            // batches keep 4+ workgroups per CU (measured 17-ch: 0.45 -> 0.42 ms)
+  // One-record colours, unsegmented lists (round 5): slot 0 of every batch is a NULL record (opacity 0, empty box) and a batch stages
+  // FB - 1 splats into slots 1 .. FB - 1.  The rows' lists start out as zeros, so the steps the lock-step loop runs past a row's own
+  // count composite the null record - no per-step "is this row still active" compare.  (Segment boundaries are multiples of the
+  // batch size: the segmented variants keep FB splats per batch and the compare.)
+#ifndef D4GS_FWD_NULL0
+#define D4GS_FWD_NULL0 1
+#endif
+  constexpr bool NULL0 = D4GS_FWD_NULL0 && DV == 1 && !SEG;
+  constexpr int FBE = NULL0 ? FB - 1 : FB;  // splats per batch
   __shared__ float4 sg0[FB];
   __shared__ float4 sg1[FB];
   __shared__ typename BoxT<(DV <= 1)>::type sbox[FB];  // tight box in tile-local pixels
@@ -174,11 +183,16 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       for (int c = 0; c < NCH; c++) p[(1 + c) * 256] = acc[c];
     }
   };
-  for (int b = start; b < end; b += FB) {
+  for (int b = start; b < end; b += FBE) {
     if (__syncthreads_and(done)) break;  // also orders the previous batch's LDS reads before restaging
     D4GS_TCLK(_ta)
-    const int idx = b + tid;
-    if (tid < FB && idx < end) {
+    const int idx = b + tid - (NULL0 ? 1 : 0);
+    if (NULL0 && tid == 0) {
+      sg0[0] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255 at every pixel
+      sg1[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      sbox[0] = BoxT<PB>::pack(1e30f, -1e30f, 1e30f, -1e30f);
+      scol[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (tid < FB && idx < end) {
       const int gid = a.sorted_gid[idx];
       const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
       const float4 q0 = gp[0], q1 = gp[1];
@@ -200,7 +214,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     __syncthreads();
     D4GS_TCLK(_tb)
     D4GS_TADD(_ts, _ta, _tb)
-    const int nb = min(FB, end - b);
+    const int nb = min(FBE, end - b) + (NULL0 ? 1 : 0);  // slots in use
     // ---- per-row lists of this wave's quadrant ----
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // wave-uniform list lengths
     // The wave's four lists start out as zeros (one 16-byte store per lane and batch): the composite loop reads list bytes past a
@@ -243,12 +257,12 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       const float dx = g0.x - pxf, dy = g0.y - pyf;
       const float sigma = splat_sigma2(g1, dx, dy);  // sigma * log2(e)
       const float alpha = fminf(0.999f, g0.z * __builtin_amdgcn_exp2f(-sigma));
-      const float nT = T * (1.f - alpha);
+      const float nT = T * (1.f - alpha);  // (as one FMA, T - alpha T: measured 1 % of this kernel, not worth leaving the reference's rounding)
       // The lane masks are handled as what they are - 64-bit scalars: ONE compare against the saturation threshold feeds both the
       // composite (as it is) and `done` (its complement, a scalar and-not).  Written with bools the compiler issues that compare twice
       // (v_cmp_ge + v_cmp_nge / v_cmp_lt + v_cmp_nlt).
       // (one ballot per compare: the ballot of a conjunction is lowered through a VGPR - v_cndmask + v_cmp_ne)
-      const unsigned long long vm = actm & __builtin_amdgcn_ballot_w64(sigma >= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= (1.f / 255.f)) & ~donem;
+      const unsigned long long vm = (NULL0 ? ~0ull : actm) & __builtin_amdgcn_ballot_w64(sigma >= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= (1.f / 255.f)) & ~donem;
       const unsigned long long mm = __builtin_amdgcn_ballot_w64(nT > 1e-4f);  // (hip's __ballot goes through an int: v_cndmask + v_cmp)
       donem |= vm & ~mm;
       const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm & mm);
@@ -277,10 +291,10 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
         const int i1 = min(i0 + 16, imax);
         for (int i = i0; i < i1; i += 4) {
           const uint32_t w4 = *reinterpret_cast<const uint32_t *>(mylist + i);
-          step(__builtin_amdgcn_ballot_w64(i < cnt), d4gs_byte_x16<0>(w4));
-          step(__builtin_amdgcn_ballot_w64(i + 1 < cnt), d4gs_byte_x16<1>(w4));
-          step(__builtin_amdgcn_ballot_w64(i + 2 < cnt), d4gs_byte_x16<2>(w4));
-          step(__builtin_amdgcn_ballot_w64(i + 3 < cnt), d4gs_byte_x16<3>(w4));
+          step(NULL0 ? 0ull : __builtin_amdgcn_ballot_w64(i < cnt), d4gs_byte_x16<0>(w4));
+          step(NULL0 ? 0ull : __builtin_amdgcn_ballot_w64(i + 1 < cnt), d4gs_byte_x16<1>(w4));
+          step(NULL0 ? 0ull : __builtin_amdgcn_ballot_w64(i + 2 < cnt), d4gs_byte_x16<2>(w4));
+          step(NULL0 ? 0ull : __builtin_amdgcn_ballot_w64(i + 3 < cnt), d4gs_byte_x16<3>(w4));
         }
         if (donem == ~0ull) break;
       }
@@ -319,7 +333,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
         if (__all(done)) break;
       }
     }
-    last = last16 >= 0 ? b + (last16 >> 4) : last;  // list index of the batch's last contributor, formed once per batch
+    last = last16 >= 0 ? b + (last16 >> 4) - (NULL0 ? 1 : 0) : last;  // list index of the batch's last contributor, formed once per batch
     has_last = has_last || last16 >= 0;
     D4GS_TCLK(_tc1)
     D4GS_TADD(_tc, _tc0, _tc1)
