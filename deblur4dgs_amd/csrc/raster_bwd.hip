@@ -135,7 +135,7 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
   __shared__ float4 sg1[NB];
   __shared__ typename std::conditional<W4, uint2, float4>::type sbox[NB];  // W4: 4 x f16, tile-local (the forward's pack_box)
   __shared__ float4 scol[NB * DV];
-  __shared__ float sgrad[4 * NB * RP];
+  __shared__ __attribute__((aligned(16))) float sgrad[4 * NB * RP];
   __shared__ int shi[4];
 
   D4GS_TRACE_BEGIN
@@ -318,7 +318,14 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
         }
       }
     }
-    for (int z = tid; z < 4 * NB * RP; z += 256) sgrad[z] = 0.f;
+#ifndef D4GS_BWD_ZERO128
+#define D4GS_BWD_ZERO128 1
+#endif
+    if constexpr (D4GS_BWD_ZERO128) {  // 16 bytes per store (4 * NB * RP floats = 64 RP float4)
+      for (int z = tid; z < NB * RP; z += 256) reinterpret_cast<float4 *>(sgrad)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int z = tid; z < 4 * NB * RP; z += 256) sgrad[z] = 0.f;
+    }
     __syncthreads();
     const int nb = min(NB, bh - start + 1);
 #pragma unroll
@@ -400,14 +407,25 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
       }
       const float4 g1 = sg1[tid];  // conic * log2(e), 1 / opacity
       float *dst = a.isect_grad + (size_t)emit * R;
-      dst[0] = (2.f * g1.x * sum[0] + g1.y * sum[1]) * LN2;  // dL/dx = a Sum(vs dx) + b Sum(vs dy); g1 = (a/2, b, c/2) log2e
-      dst[1] = (g1.y * sum[0] + 2.f * g1.z * sum[1]) * LN2;
-      dst[2] = 0.5f * sum[2];
-      dst[3] = sum[3];
-      dst[4] = 0.5f * sum[4];
-      dst[5] = -sum[5] * g1.w;
+      const float o0 = (2.f * g1.x * sum[0] + g1.y * sum[1]) * LN2;  // dL/dx = a Sum(vs dx) + b Sum(vs dy); g1 = (a/2, b, c/2) log2e
+      const float o1 = (g1.y * sum[0] + 2.f * g1.z * sum[1]) * LN2;
+      if constexpr (R % 2 == 0 && R <= 12) {  // even rows start on 8-byte boundaries: half as many stores (narrow rows only: registers)
+        float2 *d2 = reinterpret_cast<float2 *>(dst);
+        d2[0] = make_float2(o0, o1);
+        d2[1] = make_float2(0.5f * sum[2], sum[3]);
+        d2[2] = make_float2(0.5f * sum[4], -sum[5] * g1.w);
 #pragma unroll
-      for (int c = 0; c < NCH; c++) dst[6 + c] = sum[6 + c];
+        for (int c = 0; c < NCH; c += 2) d2[3 + c / 2] = make_float2(sum[6 + c], sum[7 + c]);
+      } else {
+        dst[0] = o0;
+        dst[1] = o1;
+        dst[2] = 0.5f * sum[2];
+        dst[3] = sum[3];
+        dst[4] = 0.5f * sum[4];
+        dst[5] = -sum[5] * g1.w;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) dst[6 + c] = sum[6 + c];
+      }
       if (a.sparse) a.live[emit] = 1;
     }
   }
