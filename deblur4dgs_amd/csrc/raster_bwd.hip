@@ -224,6 +224,17 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
   }
   // last contributor of this quadrant / of the tile
   int whi = last < start ? start - 1 : last;
+  // ... and of each of the quadrant's four 4x4 blocks (round 5): a staged splat is replayed only if its box reaches a block that still
+  // has a contributor at or behind it.  The replays this prunes lit no lane (the pixels inside the box were all saturated in front
+  // of the splat, the others fail the alpha test), so the rows are the same bit for bit.
+#ifndef D4GS_BWD_BLOCK_LAST
+#define D4GS_BWD_BLOCK_LAST 1
+#endif
+  int wq = whi;  // after xor 1, 2 (x within the block) and 8, 16 (y within the block): the lane's own block
+#pragma unroll
+  for (int o = 1; o <= 16; o = o == 2 ? 8 : o << 1) wq = max(wq, __shfl_xor(wq, o));
+  const int wq0 = __builtin_amdgcn_readlane(wq, 0), wq1 = __builtin_amdgcn_readlane(wq, 4), wq2 = __builtin_amdgcn_readlane(wq, 32),
+            wq3 = __builtin_amdgcn_readlane(wq, 36);  // blocks (x, y) = (0, 0), (1, 0), (0, 1), (1, 1)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) whi = max(whi, __shfl_xor(whi, o));
   whi = min(whi, end - 1);
@@ -336,7 +347,14 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
         float4 bx;
         if constexpr (W4) bx = d4gs_unpack_box(sbox[jj]);
         else bx = sbox[jj];
-        hit = (bx.x <= qhx) && (bx.y >= qlx) && (bx.z <= qhy) && (bx.w >= qly);
+        if constexpr (D4GS_BWD_BLOCK_LAST) {
+          const int cur = bh - jj;
+          const bool X0 = (bx.x <= qlx + 3.f) && (bx.y >= qlx), X1 = (bx.x <= qhx) && (bx.y >= qlx + 4.f);
+          const bool Y0 = (bx.z <= qly + 3.f) && (bx.w >= qly), Y1 = (bx.z <= qhy) && (bx.w >= qly + 4.f);
+          hit = (X0 && Y0 && cur <= wq0) || (X1 && Y0 && cur <= wq1) || (X0 && Y1 && cur <= wq2) || (X1 && Y1 && cur <= wq3);
+        } else {
+          hit = (bx.x <= qhx) && (bx.y >= qlx) && (bx.z <= qhy) && (bx.w >= qly);
+        }
       }
       unsigned long long m = __ballot(hit);
       while (m) {
