@@ -507,9 +507,48 @@ __device__ __forceinline__ float rowsum3_packed(float a, float b, float c) {
                  : "s"(odd), "s"(l3));
   return a;
 }
+// Two folded registers (R = 6 / 7: the VALU rows of the 17-channel composite backward): after the first quad step the odd lanes take
+// the second register - 6 (7) instructions instead of 9 (15).  PAIR: the second register holds two values (rows 0,1 / 2,3), combined
+// by a row_bcast step in lanes 12..15; otherwise it already holds one value per row.
+template <bool PAIR>
+__device__ __forceinline__ float rowsum2_packed(float a, float b) {
+  const uint64_t odd = 0xaaaaaaaaaaaaaaaaull;
+  if constexpr (PAIR)
+    asm volatile("s_nop 1\n\t" D4GS_DA(0, D4GS_C1) D4GS_DA(1, D4GS_C1) "v_cndmask_b32_e64 %0, %0, %1, %2\n\ts_nop 1\n\t" D4GS_DA(0, D4GS_C2)
+                 "s_nop 1\n\t" D4GS_DA(0, D4GS_C7) "s_nop 1\n\t" D4GS_DA(0, D4GS_C8) "s_nop 1\n\t" D4GS_DA(0, D4GS_C5S)
+                 : "+v"(a), "+v"(b)
+                 : "s"(odd));
+  else
+    asm volatile("s_nop 1\n\t" D4GS_DA(0, D4GS_C1) D4GS_DA(1, D4GS_C1) "v_cndmask_b32_e64 %0, %0, %1, %2\n\ts_nop 1\n\t" D4GS_DA(0, D4GS_C2)
+                 "s_nop 1\n\t" D4GS_DA(0, D4GS_C7) "s_nop 1\n\t" D4GS_DA(0, D4GS_C8)
+                 : "+v"(a), "+v"(b)
+                 : "s"(odd));
+  return a;
+}
+// Slab slots written for R values: R, except R = 7 through the packed ladder, whose last value arrives as two partial sums in slots 6
+// and 7 (the reader adds them).
+template <int R>
+constexpr bool d4gs_wave_sum_split_last() { return D4GS_PACKED_LADDER && R == 7; }
 template <int R>
 __device__ __forceinline__ void wave_sum_store(float (&v)[R], float *arr, int at, int lane) {
   constexpr int n4 = R / 4, rem = R % 4, n2 = rem / 2, n1 = rem % 2, NR = n4 + n2 + n1;
+  if constexpr (D4GS_PACKED_LADDER && n4 == 1 && n2 == 1) {  // R = 6, 7
+    const float z0 = swap16_add(swap32_add(v[0], v[1]), swap32_add(v[2], v[3]));  // rows (v0, v2, v1, v3)
+    const float t = swap32_add(v[4], v[5]);                                        // lanes 0..31 v4, 32..63 v5
+    const int r = lane >> 4, k = lane & 15;
+    const int o4 = ((r & 1) << 1) | (r >> 1);
+    int ats = at;
+    asm volatile("" : "+s"(ats));
+    if constexpr (n1) {
+      // the seventh value rides unfolded: rows (v4, v6 lower half, v5, v6 upper half) -> slots 4, 6, 5, 7
+      const float q = rowsum2_packed<false>(z0, swap16_add(t, v[6]));
+      if (k < 2) arr[ats + (k == 0 ? o4 : (r == 0 ? 4 : r == 1 ? 6 : r == 2 ? 5 : 7))] = q;
+    } else {
+      const float q = rowsum2_packed<true>(z0, t);
+      if (k == 0 || (k == 15 && (r & 1))) arr[ats + (k == 0 ? o4 : 4 + (r >> 1))] = q;
+    }
+    return;
+  }
   float z[NR];
 #pragma unroll
   for (int g = 0; g < n4; g++)

@@ -422,6 +422,10 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
       for (int r = 0; r < R; r++) {
         const int q = !MC || r < 6 ? r : (r - 6 < MC ? CB + r - 6 : r - MC);
         sum[r] = (sgrad[tid * RP + q] + sgrad[(NB + tid) * RP + q]) + (sgrad[(2 * NB + tid) * RP + q] + sgrad[(3 * NB + tid) * RP + q]);
+        if constexpr (d4gs_wave_sum_split_last<RV>()) {  // (wave_sum_store: the last VALU row arrives as two partial sums, slots RV - 1 and RV)
+          if (q == RV - 1)
+            sum[r] += (sgrad[tid * RP + RV] + sgrad[(NB + tid) * RP + RV]) + (sgrad[(2 * NB + tid) * RP + RV] + sgrad[(3 * NB + tid) * RP + RV]);
+        }
       }
       const float4 g1 = sg1[tid];  // conic * log2(e), 1 / opacity
       float *dst = a.isect_grad + (size_t)emit * R;
