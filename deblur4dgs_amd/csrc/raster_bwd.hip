@@ -262,12 +262,16 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
     if constexpr (MC > 0) {
       __builtin_amdgcn_wave_barrier();
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // even / odd k-steps, added in fixed order
-      const bool col = (lane & 15) < MH;  // (MH = 8: columns 8..15 of the B operand are zeros)
-      const float *bp = myfac + (lane >> 4) * FS + (col ? (lane & 15) : 0);
+      // MH = 8: columns 8..15 of the B operand repeat columns 0..7 (their products are never stored) - plain loads, all sixteen in
+      // flight, instead of sixteen exec-masked ones each waited for in front of its MFMA
+      const float *bp = myfac + (lane >> 4) * FS + (lane & (MH - 1));
+      float bv[16];
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) bv[kk] = bp[4 * kk * FS];
 #pragma unroll
       for (int kk = 0; kk < 16; kk += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], col ? bp[4 * kk * FS] : 0.f, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk + 1], col ? bp[(4 * kk + 4) * FS] : 0.f, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], bv[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk + 1], bv[kk + 1], acc1, 0, 0, 0);
       }
       acc0 += acc1;
       const int n = lane & 15;
