@@ -69,9 +69,6 @@ for a0 in range(0, n, CH):
     geo = (sig >= 0) & (alpha >= 1 / 255) & inimg
     gq = geo.view(-1, 2, 8, 2, 8).permute(0, 1, 3, 2, 4).reshape(-1, 4, 64).sum(-1)
     lastq = lastp.reshape(-1, 2, 8, 2, 8).permute(0, 1, 3, 2, 4).reshape(-1, 4, 64).max(-1).values
-    hit_k = hit & (idx_in_list[sl, None] <= lastq)            # what the backward kernel replays today
-    K_hits += int(hit_k.sum()); K_zero += int((vq[hit_k] == 0).sum()); K_geo_zero += int((gq[hit_k] == 0).sum())
-    K_valid = (K_valid if "K_valid" in globals() else 0) + int(vq[hit_k].sum())
     gb = geo.view(-1, 4, 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 16, 16).sum(-1)
     lastb = lastp.reshape(-1, 4, 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 16, 16).max(-1).values
     # ---- 4x4 blocks: 16 per tile; row r of quadrant q handles block (q, r)
@@ -88,6 +85,13 @@ for a0 in range(0, n, CH):
                           (bhit & (vb > 0)).long(), accumulate=True)
     ti16 = (tile_of[sl][:, None].expand(-1, 16), torch.arange(16, device=dev)[None].expand(bhit.shape[0], -1))
     bk = bhit & (idx_in_list[sl, None] <= lastb)
+    # what the backward kernel replays (round 5): the box reaches a 4x4 block of the quadrant that still has a contributor at or
+    # behind the splat (until round 5: box & <= the QUADRANT's last contributor - `hit_kq`)
+    hit_kq = hit & (idx_in_list[sl, None] <= lastq)
+    hit_k = bk.view(-1, 2, 2, 2, 2).permute(0, 1, 3, 2, 4).reshape(-1, 4, 4).any(-1) & hit_kq
+    KQ_hits = (KQ_hits if "KQ_hits" in globals() else 0) + int(hit_kq.sum())
+    K_hits += int(hit_k.sum()); K_zero += int((vq[hit_k] == 0).sum()); K_geo_zero += int((gq[hit_k] == 0).sum())
+    K_valid = (K_valid if "K_valid" in globals() else 0) + int(vq[hit_k].sum())
     blk_len_k.index_put_(ti16, bk.long(), accumulate=True)
     blk_len_g.index_put_(ti16, (bk & (gb > 0)).long(), accumulate=True)
     q_len_g.index_put_((tile_of[sl][:, None].expand(-1, 4), torch.arange(4, device=dev)[None].expand(hit.shape[0], -1)),
@@ -121,7 +125,7 @@ bl2 = blk_len_nz.view(-1, 2, 2, 2, 2).permute(0, 1, 3, 2, 4).reshape(-1, 4, 4)
 print(f"   with an exact (non-empty only) block test: sum of max {int(bl2.max(-1).values.sum())}")
 # alternative: 8 rows of 8 lanes?  2x4 px blocks are too small; alternative 16 lanes = 8x2? skip
 
-print(f"bwd kernel today: quadrant replays (box & <= quadrant last) {K_hits}; zero-valid {K_zero / K_hits:.3f}; zero by geometry alone {K_geo_zero / K_hits:.3f}")
+print(f"bwd kernel today: quadrant replays (box reaches a 4x4 block with a contributor at or behind the splat) {K_hits} (with the quadrant's last contributor only: {KQ_hits}); zero-valid {K_zero / K_hits:.3f}; zero by geometry alone {K_geo_zero / K_hits:.3f}")
 print(f"   quadrant replays with an exact ellipse test: {int(q_len_g.sum())}")
 def summax(t):
     return int(t.view(-1, 2, 2, 2, 2).permute(0, 1, 3, 2, 4).reshape(-1, 4, 4).max(-1).values.sum())
