@@ -508,31 +508,82 @@ __global__ void __launch_bounds__(COUNT_THREADS) k_count_tiles(const int *__rest
   int *hist2 = hist + tiles;
   const uint32_t zlo = LAZY ? ~lazy.zr[2 * s] : 0u, zhi = LAZY ? lazy.zr[2 * s + 1] : 0u;
   int touched = 0;  // this lane's share of the chunk's intersection count (fused scan: see d4gs_fused_scan)
-#pragma unroll
-  for (int q = 0; q < COUNT_PER_THREAD; q++) {
-    const int g = (chunk * COUNT_PER_THREAD + q) * COUNT_THREADS + tid;
-    if (g >= N) continue;
-    const size_t i = (size_t)s * N + g;
-    const int tt = tiles_touched[i];
-    touched += tt;
-    if (tt == 0) continue;
-    const int2 rc = *reinterpret_cast<const int2 *>(tile_rects + i * 2);
-    const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
-    const int bk = LAZY ? d4gs_depth_bucket(depths[i], zlo, zhi, lazy.nb) : 0;
-    const uint64_t mask = tile_masks ? tile_masks[i] : 0;
-    if (mask) {  // D4GS_EXACT_TILES: the tiles the ellipse reaches, bit (ty - y0) * 8 + (tx - x0)
-      for (uint64_t m = mask; m; m &= m - 1) {
-        const int b = __ffsll((long long)m) - 1, t = (y0 + (b >> 3)) * tw + x0 + (b & 7);
-        atomicAdd(&hist[t], 1);
-        if (LAZY) atomicAdd(&hist2[t * lazy.nb + bk], 1);
+  if constexpr (LAZY) {
+    // (the lazy instantiation - cfg5: a 150 KB histogram, ONE resident workgroup per CU - keeps the instance-by-instance walk: with all
+    // loads up front its sixteen waves load together and then hammer the LDS together, 199 -> 226 us)
+  #pragma unroll
+    for (int q = 0; q < COUNT_PER_THREAD; q++) {
+      const int g = (chunk * COUNT_PER_THREAD + q) * COUNT_THREADS + tid;
+      if (g >= N) continue;
+      const size_t i = (size_t)s * N + g;
+      const int tt = tiles_touched[i];
+      touched += tt;
+      if (tt == 0) continue;
+      const int2 rc = *reinterpret_cast<const int2 *>(tile_rects + i * 2);
+      const int x0 = rc.x & 0xffff, x1 = rc.x >> 16, y0 = rc.y & 0xffff, y1 = rc.y >> 16;
+      const int bk = LAZY ? d4gs_depth_bucket(depths[i], zlo, zhi, lazy.nb) : 0;
+      const uint64_t mask = tile_masks ? tile_masks[i] : 0;
+      if (mask) {  // D4GS_EXACT_TILES: the tiles the ellipse reaches, bit (ty - y0) * 8 + (tx - x0)
+        for (uint64_t m = mask; m; m &= m - 1) {
+          const int b = __ffsll((long long)m) - 1, t = (y0 + (b >> 3)) * tw + x0 + (b & 7);
+          atomicAdd(&hist[t], 1);
+          if (LAZY) atomicAdd(&hist2[t * lazy.nb + bk], 1);
+        }
+        continue;
       }
-      continue;
+      for (int ty = y0; ty < y1; ty++)
+        for (int tx = x0; tx < x1; tx++) {
+          atomicAdd(&hist[ty * tw + tx], 1);
+          if (LAZY) atomicAdd(&hist2[(ty * tw + tx) * lazy.nb + bk], 1);
+        }
     }
-    for (int ty = y0; ty < y1; ty++)
-      for (int tx = x0; tx < x1; tx++) {
-        atomicAdd(&hist[ty * tw + tx], 1);
-        if (LAZY) atomicAdd(&hist2[(ty * tw + tx) * lazy.nb + bk], 1);
+  } else {
+    // (all of the lane's loads first, waited for once - k_emit's note in binning.hip: instance by instance this was 2 x COUNT_PER_THREAD
+    // dependent round trips to memory)
+    int tts[COUNT_PER_THREAD], rxs[COUNT_PER_THREAD], rys[COUNT_PER_THREAD];
+    float deps[COUNT_PER_THREAD];
+    uint64_t msks[COUNT_PER_THREAD];
+  #pragma unroll
+    for (int q = 0; q < COUNT_PER_THREAD; q++) {
+      const int g = (chunk * COUNT_PER_THREAD + q) * COUNT_THREADS + tid;
+      tts[q] = 0, rxs[q] = 0, rys[q] = 0, deps[q] = 0.f, msks[q] = 0;
+      if (g < N) {
+        const size_t i = (size_t)s * N + g;
+        tts[q] = tiles_touched[i];
+        const int2 rc = *reinterpret_cast<const int2 *>(tile_rects + i * 2);
+        rxs[q] = rc.x, rys[q] = rc.y;
+        if (LAZY) deps[q] = depths[i];
+        if (tile_masks) msks[q] = tile_masks[i];
       }
+    }
+  #pragma unroll
+    for (int q = 0; q < COUNT_PER_THREAD; q++) {
+      uint32_t ml = (uint32_t)msks[q], mh = (uint32_t)(msks[q] >> 32);
+      asm volatile("" : "+v"(tts[q]), "+v"(rxs[q]), "+v"(rys[q]), "+v"(deps[q]), "+v"(ml), "+v"(mh));
+      msks[q] = ((uint64_t)mh << 32) | ml;
+    }
+  #pragma unroll
+    for (int q = 0; q < COUNT_PER_THREAD; q++) {
+      const int tt = tts[q];
+      touched += tt;
+      if (tt == 0) continue;
+      const int x0 = rxs[q] & 0xffff, x1 = rxs[q] >> 16, y0 = rys[q] & 0xffff, y1 = rys[q] >> 16;
+      const int bk = LAZY ? d4gs_depth_bucket(deps[q], zlo, zhi, lazy.nb) : 0;
+      const uint64_t mask = msks[q];
+      if (mask) {  // D4GS_EXACT_TILES: the tiles the ellipse reaches, bit (ty - y0) * 8 + (tx - x0)
+        for (uint64_t m = mask; m; m &= m - 1) {
+          const int b = __ffsll((long long)m) - 1, t = (y0 + (b >> 3)) * tw + x0 + (b & 7);
+          atomicAdd(&hist[t], 1);
+          if (LAZY) atomicAdd(&hist2[t * lazy.nb + bk], 1);
+        }
+        continue;
+      }
+      for (int ty = y0; ty < y1; ty++)
+        for (int tx = x0; tx < x1; tx++) {
+          atomicAdd(&hist[ty * tw + tx], 1);
+          if (LAZY) atomicAdd(&hist2[(ty * tw + tx) * lazy.nb + bk], 1);
+        }
+    }
   }
   if (chunk_sums) {
 #pragma unroll
