@@ -365,7 +365,16 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
         const int j = k * 64 + (__ffsll((long long)m) - 1);
         m &= m - 1;
         const int cur = bh - j;
-        const float4 g0 = sg0[j], g1 = sg1[j];
+#ifndef D4GS_BWD_PIN_ADDR
+#define D4GS_BWD_PIN_ADDR 1
+#endif
+        // narrow kernels: the staged records' byte offset in ONE pinned VGPR for all three reads (the compiler re-materialised it from
+        // the scalar for the read behind the early-out): 627 -> 619 us on cfg2.  (The 17-channel kernel got SLOWER with it, and with g0
+        // as one 16-byte read instead of 12 + 4: 888 -> 926 us on refdefault - it keeps the plain indexing.)
+        int jb = j * 16;
+        if constexpr (D4GS_BWD_PIN_ADDR && MC == 0) asm volatile("" : "+v"(jb));
+        const float4 g0 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sg0) + jb);
+        const float4 g1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sg1) + jb);
         const float dx = g0.x - pxf, dy = g0.y - pyf;
         const float sig2 = splat_sigma2(g1, dx, dy);
         const float ov = g0.z * __builtin_amdgcn_exp2f(-sig2);
@@ -380,7 +389,7 @@ __device__ __forceinline__ void raster_bwd_q_body(const RasterBwdArgs &a) {
         float d = 0.f;
 #pragma unroll
         for (int v = 0; v < DV; v++) {
-          const float4 c4 = scol[j * DV + v];
+          const float4 c4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(scol) + jb * DV + 16 * v);
           constexpr int DC = D + ((DEPTH && (D & 3) != 0) ? 1 : 0);  // channels the record holds (vo[D] = the depth channel)
           if (v * 4 < DC) d = __builtin_fmaf(vo[v * 4], c4.x, d);
           if (v * 4 + 1 < DC) d = __builtin_fmaf(vo[v * 4 + 1], c4.y, d);
