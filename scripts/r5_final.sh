@@ -5,7 +5,7 @@ tag=r05s
 mkdir -p gpurun_out
 R=$PWD
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee gpurun_out/${tag}_pytest_gpu.txt
+timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -6 | tee gpurun_out/${tag}_pytest_gpu.txt
 cp gpurun_out/parity_table.md gpurun_out/${tag}_parity_table.md 2>/dev/null; cp gpurun_out/parity_table.json gpurun_out/${tag}_parity_table.json 2>/dev/null
 python __graft_entry__.py smoke 2>&1 | tail -2 | tee gpurun_out/${tag}_smoke.txt
 python scripts/mock_upstream_fixture.py gpurun_out/mock_upstream > /dev/null 2>&1
