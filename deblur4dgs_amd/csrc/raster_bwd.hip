@@ -919,3 +919,43 @@ int d4gs_raster_bwd_impl(const D4gsDims *dims, const D4gsProjOut *proj, const D4
   }
 #undef D4GS_CASE
 }
+
+#ifdef D4GS_VARIANTS
+// Test hook of the A/B build only (tests/libd4gs_variants.so, tests/test_gpu_wave_sum.py): ONE wave sums R per-lane values over its 64
+// lanes with wave_sum_store - every folding / ladder pattern the kernels instantiate (and the ones they do not), in the slot order the
+// callers rely on.
+namespace {
+template <int R>
+__global__ void __launch_bounds__(64) k_test_wave_sum(const float *in, float *out) {
+  __shared__ float slab[32];
+  const int lane = threadIdx.x;
+  float v[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) v[r] = in[lane * R + r];
+  if (lane < 32) slab[lane] = 0.f;
+  __syncthreads();
+  wave_sum_store(v, slab, 0, lane);
+  __syncthreads();
+  if (lane < R) {
+    float s = slab[lane];
+    if (d4gs_wave_sum_split_last<R>() && lane == R - 1) s += slab[R];
+    out[lane] = s;
+  }
+}
+}  // namespace
+extern "C" D4GS_API int d4gs_test_wave_sum(int R, const float *in, float *out, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+#define D4GS_WS(RR) \
+  case RR:          \
+    hipLaunchKernelGGL(k_test_wave_sum<RR>, dim3(1), dim3(64), 0, st, in, out); \
+    break;
+  switch (R) {
+    D4GS_WS(1) D4GS_WS(2) D4GS_WS(3) D4GS_WS(4) D4GS_WS(5) D4GS_WS(6) D4GS_WS(7) D4GS_WS(8) D4GS_WS(9) D4GS_WS(10) D4GS_WS(11) D4GS_WS(12)
+    D4GS_WS(13) D4GS_WS(14) D4GS_WS(15) D4GS_WS(16) D4GS_WS(17) D4GS_WS(21) D4GS_WS(22) D4GS_WS(23)
+    default:
+      return D4GS_EINVAL;
+  }
+#undef D4GS_WS
+  return hipGetLastError() == hipSuccess ? 0 : D4GS_ELAUNCH;
+}
+#endif
