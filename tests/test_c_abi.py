@@ -40,6 +40,8 @@ def test_dynamic_symbol_table_is_exactly_the_header(lib):
     for path in (build.LIB, build.build_variants()):
         out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
         syms = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+        if path != build.LIB:  # the A/B build may carry test hooks (d4gs_test_*: tests/test_gpu_wave_sum.py); the product library may not
+            syms = [x for x in syms if not x.startswith("d4gs_test_")]
         assert syms == _declared(), (path, sorted(set(syms) ^ set(_declared())))
 
 
