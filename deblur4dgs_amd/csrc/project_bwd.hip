@@ -24,6 +24,7 @@
 #ifndef D4GS_PACKED_LADDER
 #define D4GS_PACKED_LADDER 0
 #endif
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -109,6 +110,19 @@ __global__ void __launch_bounds__(256) k_bases_table(const D4gsDims d, const flo
     btab[((size_t)s * K + k) * 16 + j] = v;
   }
 }
+// A kernel argument read afresh from the kernarg segment where it is used (s_load at the use site).  k_project_bwd sits at the SGPR limit:
+// its ~370-byte argument block was loaded at entry and ~130 of those values were parked in VGPR lanes (v_writelane) and restored with
+// v_readlane, 16-register tuples at a time - ~170 restores in the per-group epilogue alone.  The epilogue's pointers are read with this.
+#ifndef PB_KARG_RELOAD
+#define PB_KARG_RELOAD 1
+#endif
+template <typename T>
+__device__ __forceinline__ T pb_karg_at(size_t off) {
+  typedef const volatile __attribute__((address_space(4))) T *kp;
+  const __attribute__((address_space(4))) char *base = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(kp)(base + off);
+}
+#define PB_KARG(f_) (PB_KARG_RELOAD ? pb_karg_at<std::remove_cv_t<std::remove_reference_t<decltype(a.f_)>>>((size_t)((const char *)&(a.f_) - (const char *)&a)) : a.f_)
 typedef const __attribute__((address_space(4))) float *cfloat_p;
 #define PB_BROW(k_) ((cfloat_p)(uintptr_t)a.btab + ((size_t)s * K + (k_)) * 16)
 template <int MODE, bool MFMA /* K > 8: basis-gradient column sums on the matrix pipe */, int SL /* slots per sub-group */>
@@ -153,28 +167,33 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   const bool isdyn = active && g < G;
 
   float mu[3] = {0, 0, 0}, sc[3] = {1, 1, 1}, qh[4] = {1, 0, 0, 0}, inv_qn = 1.f;
-  if (active) mu[0] = a.in.means[g * 3], mu[1] = a.in.means[g * 3 + 1], mu[2] = a.in.means[g * 3 + 2];
+  if (active) {
+    const float *const i_means = PB_KARG(in.means);
+    mu[0] = i_means[g * 3], mu[1] = i_means[g * 3 + 1], mu[2] = i_means[g * 3 + 2];
+  }
   const bool need_q = MODE == MODE_RENDER || a.v_quats_out != nullptr;
   if (active && need_q) {
-    const float4 q = *reinterpret_cast<const float4 *>(a.in.quats + (size_t)g * 4);
+    const float4 q = *reinterpret_cast<const float4 *>(PB_KARG(in.quats) + (size_t)g * 4);
     inv_qn = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
     qh[0] = q.x * inv_qn, qh[1] = q.y * inv_qn, qh[2] = q.z * inv_qn, qh[3] = q.w * inv_qn;
   }
   if (MODE == MODE_RENDER && active) {
+    const float *const i_scales = PB_KARG(in.scales);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      float v = a.in.scales[g * 3 + j];
+      float v = i_scales[g * 3 + j];
       sc[j] = raw ? expf(v) : v;
     }
   }
   if (dyn_block) {
     for (int k = 0; k < K; k++) vcf[tid * KP + k] = 0.f;
     if (slot == 0) {  // softmax(motion_coefs) params.py:43, once per Gaussian
+      const float *const i_coefs = PB_KARG(in.motion_coefs);
       for (int k = 0; k < K; k++) cfl[k] = 0.f;
       if (MODE == MODE_POSES && isdyn && !raw) {  // activated coefficients, used as given
-        for (int k = 0; k < K; k++) cfl[k] = a.in.motion_coefs[(size_t)g * K + k];
+        for (int k = 0; k < K; k++) cfl[k] = i_coefs[(size_t)g * K + k];
       } else if (isdyn) {
-        const float *mc = a.in.motion_coefs + (size_t)g * K;
+        const float *mc = i_coefs + (size_t)g * K;
         float m = -INFINITY;
         for (int k = 0; k < K; k++) m = fmaxf(m, mc[k]);
         float sum = 0.f;
@@ -214,11 +233,12 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
     int radius = 0;
     float in_con[3] = {0, 0, 0}, in_vcon[3] = {0, 0, 0}, in_vm2[2] = {0, 0}, in_vdep = 0.f;
     if (MODE == MODE_RENDER && active) {
-      radius = a.radii[i];
+      radius = PB_KARG(radii)[i];
+      const float *const i_con = PB_KARG(conics), *const i_vcon = PB_KARG(v_conics), *const i_vm2 = PB_KARG(v_means2d);
 #pragma unroll
-      for (int c = 0; c < 3; c++) in_con[c] = a.conics[i * 3 + c], in_vcon[c] = a.v_conics[i * 3 + c];
-      in_vm2[0] = a.v_means2d[i * 2], in_vm2[1] = a.v_means2d[i * 2 + 1];
-      in_vdep = a.v_depths[i];
+      for (int c = 0; c < 3; c++) in_con[c] = i_con[i * 3 + c], in_vcon[c] = i_vcon[i * 3 + c];
+      in_vm2[0] = i_vm2[i * 2], in_vm2[1] = i_vm2[i * 2 + 1];
+      in_vdep = PB_KARG(v_depths)[i];
     }
     if (active) {
       // The chain is written phase by phase with scheduling fences (SB) between the phases: left alone, the scheduler
@@ -591,23 +611,26 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
   };
   // ---- per-Gaussian leaves: the sub-group's SL waves split the four tensor groups (group p goes to slot p % SL) ----
   if (slot == 0) {
-    a.g.v_means[g * 3] = slots4(0), a.g.v_means[g * 3 + 1] = slots4(1), a.g.v_means[g * 3 + 2] = slots4(2);
+    float *const o_means = PB_KARG(g.v_means);
+    o_means[g * 3] = slots4(0), o_means[g * 3 + 1] = slots4(1), o_means[g * 3 + 2] = slots4(2);
     if (MODE == MODE_RENDER) {
+      float *const o_scales = PB_KARG(g.v_scales);
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const float v = slots4(7 + j);  // accumulated as sc * dL/dsc
-        a.g.v_scales[g * 3 + j] = raw ? v : v / sc[j];
+        o_scales[g * 3 + j] = raw ? v : v / sc[j];
       }
     }
   }
   if (slot == 1 % SL) {
-    if (need_q && a.g.v_quats) {  // adjoint of q / max(|q|, eps)
+    float *const o_quats = PB_KARG(g.v_quats);
+    if (need_q && o_quats) {  // adjoint of q / max(|q|, eps)
       const float w = qh[0], x = qh[1], y = qh[2], z = qh[3];
       const float vq0 = slots4(3), vq1 = slots4(4), vq2 = slots4(5), vq3 = slots4(6);
       const float dot = vq0 * w + vq1 * x + vq2 * y + vq3 * z;
       float4 o4 = make_float4((vq0 - dot * w) * inv_qn, (vq1 - dot * x) * inv_qn, (vq2 - dot * y) * inv_qn,
                               (vq3 - dot * z) * inv_qn);
-      *reinterpret_cast<float4 *>(a.g.v_quats + (size_t)g * 4) = o4;
+      *reinterpret_cast<float4 *>(o_quats + (size_t)g * 4) = o4;
     }
   }
   if (slot == 2 % SL) {
@@ -620,20 +643,24 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
         vr[k] = v;  // (only this lane touches its slot-0 row from here on)
         dot += cfl[k] * v;
       }
+      float *const o_coefs = PB_KARG(g.v_motion_coefs);
       for (int k = 0; k < K; k++)
-        a.g.v_motion_coefs[(size_t)g * K + k] = act ? vr[k] : cfl[k] * (vr[k] - dot);
+        o_coefs[(size_t)g * K + k] = act ? vr[k] : cfl[k] * (vr[k] - dot);
     }
   }
   if (slot == 3 % SL && MODE == MODE_RENDER) {
-    const float o = a.opac_act[g];
-    const float vo = a.v_opac_act[g];
-    a.g.v_opacities[g] = raw ? vo * o * (1.f - o) : vo;
+    const float o = PB_KARG(opac_act)[g];
+    const float vo = PB_KARG(v_opac_act)[g];
+    PB_KARG(g.v_opacities)[g] = raw ? vo * o * (1.f - o) : vo;
+    const float *const i_vctab = PB_KARG(v_ctab);
+    const float *const i_ctab = PB_KARG(ctab);
+    float *const o_colors = PB_KARG(g.v_colors);
     const int D = d.D, DP = (D + 3) & ~3;
-    const bool vec_out = (D & 3) == 0 && (((uintptr_t)a.g.v_colors) & 15) == 0;
+    const bool vec_out = (D & 3) == 0 && (((uintptr_t)o_colors) & 15) == 0;
     for (int ch = 0; ch < DP; ch += 4) {  // 16 bytes at a time (the table rows are 16-byte aligned), as in k_project_fwd
-      float4 v4 = *reinterpret_cast<const float4 *>(a.v_ctab + (size_t)g * DP + ch);
+      float4 v4 = *reinterpret_cast<const float4 *>(i_vctab + (size_t)g * DP + ch);
       if ((d.flags & D4GS_RAW_COLORS) && ch < d.n_sigmoid) {
-        const float4 c4 = *reinterpret_cast<const float4 *>(a.ctab + (size_t)g * DP + ch);
+        const float4 c4 = *reinterpret_cast<const float4 *>(i_ctab + (size_t)g * DP + ch);
         const float *cp = &c4.x;
         float *vp = &v4.x;
 #pragma unroll
@@ -641,12 +668,12 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MFMA ?
           if (ch + u < d.n_sigmoid) vp[u] *= cp[u] * (1.f - cp[u]);
       }
       if (vec_out) {
-        *reinterpret_cast<float4 *>(a.g.v_colors + (size_t)g * D + ch) = v4;
+        *reinterpret_cast<float4 *>(o_colors + (size_t)g * D + ch) = v4;
       } else {
         const float *vp = &v4.x;
 #pragma unroll
         for (int u = 0; u < 4; u++)
-          if (ch + u < D) a.g.v_colors[(size_t)g * D + ch + u] = vp[u];
+          if (ch + u < D) o_colors[(size_t)g * D + ch + u] = vp[u];
       }
     }
   }
