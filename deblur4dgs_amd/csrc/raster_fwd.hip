@@ -99,6 +99,7 @@ __device__ __forceinline__ int d4gs_byte_x16(uint32_t w) {
   if constexpr (B == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(4u), "v"(w));
   return r;
 }
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int D, bool DEPTH, bool SEG = false>
 __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 #pragma clang fp contract(off)
@@ -107,6 +108,19 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   constexpr int DV = DP / 4;
   constexpr int FB = (DV > 2 || (SEG && D4GS_SEG_UNIT < 256)) ? 128 : 256;  // splats per batch (indices fit one byte); wide colour records: smaller
                                            // batches keep 4+ workgroups per CU (measured 17-ch: 0.45 -> 0.42 ms)
+  // 16 colour channels (the reference's 17-channel training renders, round 6): the per-step update acc[c] += colour[c] * vis of
+  // channels 0..15 leaves the VALU.  It is an outer product per QUAD of lanes - the four lanes of a quad sit in one 16-lane row,
+  // i.e. composite the SAME splat - which is what v_mfma_f32_4x4x1_16b_f32 computes: lane l supplies A[i = l & 3] and B[j = l & 3]
+  // of block l >> 2 and receives D[i][l & 3] += A[i] * B[l & 3] in register i (scripts/microbench/mfma4x4.hip).  With A = colour
+  // channel 4 (l & 3) + m of the row's splat and B = the lane's own visibility, four of them (m = 0..3; 8 cycles each on the matrix
+  // pipe) replace sixteen v_fma_f32 (64+ cycles of the VALU pipe that bounds this kernel), bit for bit: one fused multiply-add
+  // per element either way.  Lane i of a quad reads float4 i of the staged record (channels 4 i .. 4 i + 3) - ONE 16-byte LDS read
+  // instead of four (the 64-byte record read by every lane was 2/3 of the step's LDS return traffic) - and MFMA m takes its
+  // component m: accm[m][i] = channel 4 i + m.
+#ifndef D4GS_FWD_MFMA
+#define D4GS_FWD_MFMA 1
+#endif
+  constexpr bool MF = D4GS_FWD_MFMA && D == 16;
   // One-record colours, unsegmented lists (round 5): slot 0 of every batch is a NULL record (opacity 0, empty box) and a batch stages
   // FB - 1 splats into slots 1 .. FB - 1.  The rows' lists start out as zeros, so the steps the lock-step loop runs past a row's own
   // count composite the null record - no per-step "is this row still active" compare.  (Segment boundaries are multiples of the
@@ -114,7 +128,11 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
 #ifndef D4GS_FWD_NULL0
 #define D4GS_FWD_NULL0 1
 #endif
-  constexpr bool NULL0 = D4GS_FWD_NULL0 && DV == 1 && !SEG;
+#ifndef D4GS_FWD_WIDE4
+#define D4GS_FWD_WIDE4 1  // the matrix-pipe kernel also takes the four-steps-per-read loop and the null record (round 6)
+#endif
+  constexpr bool LIKE_NARROW = DV == 1 || (MF && D4GS_FWD_WIDE4);
+  constexpr bool NULL0 = D4GS_FWD_NULL0 && LIKE_NARROW && !SEG;
   constexpr int FBE = NULL0 ? FB - 1 : FB;  // splats per batch
   __shared__ float4 sg0[FB];
   __shared__ float4 sg1[FB];
@@ -150,11 +168,18 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
   unsigned char *wlist = slist + wv * 4 * FB;
   const unsigned char *mylist = wlist + row * FB;
 
-  float T = 1.f, acc[NCH];
+  float T = 1.f, acc[MF ? (NCH - 16 > 0 ? NCH - 16 : 1) : NCH];  // MF: channels >= 16 only (the depth channel)
+  f32x4_t accm[MF ? 4 : 1];                                         // MF: accm[m][i] = channel 4 i + m
   int last = 0;
   bool done = !inside, has_last = false;
 #pragma unroll
-  for (int c = 0; c < NCH; c++) acc[c] = 0.f;
+  for (int c = 0; c < (MF ? NCH - 16 : NCH); c++) acc[c] = 0.f;
+#pragma unroll
+  for (int m = 0; m < (MF ? 4 : 1); m++) accm[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto chan = [&](int c) -> float {  // accumulated channel c (compile-time c: the callers' loops are unrolled)
+    if constexpr (MF) return c < 16 ? accm[c & 3][c >> 2] : acc[c - 16];
+    else return acc[c];
+  };
 
   const int start = a.tile_offsets[t];
   int end = a.tile_offsets[t + 1];
@@ -180,7 +205,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       float *p = seg_px + (size_t)k * (1 + NCH) * 256;
       p[0] = T;
 #pragma unroll
-      for (int c = 0; c < NCH; c++) p[(1 + c) * 256] = acc[c];
+      for (int c = 0; c < NCH; c++) p[(1 + c) * 256] = chan(c);
     }
   };
   for (int b = start; b < end; b += FBE) {
@@ -191,7 +216,8 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       sg0[0] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255 at every pixel
       sg1[0] = make_float4(0.f, 0.f, 0.f, 0.f);
       sbox[0] = BoxT<PB>::pack(1e30f, -1e30f, 1e30f, -1e30f);
-      scol[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int v = 0; v < DV; v++) scol[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else if (tid < FB && idx < end) {
       const int gid = a.sorted_gid[idx];
       const float4 *gp = reinterpret_cast<const float4 *>(a.geom + (inst_base + gid) * D4GS_GEOM_STRIDE);
@@ -220,7 +246,7 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     // The wave's four lists start out as zeros (one 16-byte store per lane and batch): the composite loop reads list bytes past a
     // row's count (no divergent branch in it) and takes them as they are - staged splat 0 exists in every batch, a stale index could
     // point at a never-staged record (NaN * 0) - instead of replacing them lane by lane in every step.
-    constexpr bool NARROW = DV == 1;  // one colour record: the four-steps-per-read loop below; wide records keep the one-byte loop (regs)
+    constexpr bool NARROW = LIKE_NARROW;  // one colour record (or the matrix-pipe accumulators): the four-steps-per-read loop below; other wide records keep the one-byte loop (regs)
     if constexpr (NARROW) {
       if (lane * 16 < 4 * FB) reinterpret_cast<uint4 *>(wlist)[lane] = make_uint4(0u, 0u, 0u, 0u);
       __builtin_amdgcn_wave_barrier();
@@ -267,15 +293,24 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
       donem |= vm & ~mm;
       const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm & mm);
       const float vis = valid ? alpha * T : 0.f;
+      if constexpr (MF) {
+        const float4 ct = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(scol) + j16 * DV + 16 * (lane & 3));
+        accm[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ct.x, vis, accm[0], 0, 0, 0);
+        accm[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ct.y, vis, accm[1], 0, 0, 0);
+        accm[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ct.z, vis, accm[2], 0, 0, 0);
+        accm[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(ct.w, vis, accm[3], 0, 0, 0);
+        if (DEPTH) acc[0] = __builtin_fmaf(g0.w, vis, acc[0]);
+      } else {
 #pragma unroll
-      for (int v = 0; v < DV; v++) {
-        const float4 c4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(scol) + j16 * DV + 16 * v);
-        if (v * 4 < D) acc[v * 4] = __builtin_fmaf(c4.x, vis, acc[v * 4]);
-        if (v * 4 + 1 < D) acc[v * 4 + 1] = __builtin_fmaf(c4.y, vis, acc[v * 4 + 1]);
-        if (v * 4 + 2 < D) acc[v * 4 + 2] = __builtin_fmaf(c4.z, vis, acc[v * 4 + 2]);
-        if (v * 4 + 3 < D) acc[v * 4 + 3] = __builtin_fmaf(c4.w, vis, acc[v * 4 + 3]);
+        for (int v = 0; v < DV; v++) {
+          const float4 c4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(scol) + j16 * DV + 16 * v);
+          if (v * 4 < D) acc[v * 4] = __builtin_fmaf(c4.x, vis, acc[v * 4]);
+          if (v * 4 + 1 < D) acc[v * 4 + 1] = __builtin_fmaf(c4.y, vis, acc[v * 4 + 1]);
+          if (v * 4 + 2 < D) acc[v * 4 + 2] = __builtin_fmaf(c4.z, vis, acc[v * 4 + 2]);
+          if (v * 4 + 3 < D) acc[v * 4 + 3] = __builtin_fmaf(c4.w, vis, acc[v * 4 + 3]);
+        }
+        if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
       }
-      if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
       T = valid ? nT : T;
       last16 = valid ? j16 : last16;
     };
@@ -318,15 +353,24 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
           done = done || (valid && sat);
           valid = valid && !sat;
           const float vis = valid ? alpha * T : 0.f;
+          if constexpr (MF) {
+            const float4 ct = scol[j * 4 + (lane & 3)];  // channels 4 i .. 4 i + 3, i = this lane's place in its quad
+            accm[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ct.x, vis, accm[0], 0, 0, 0);
+            accm[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ct.y, vis, accm[1], 0, 0, 0);
+            accm[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ct.z, vis, accm[2], 0, 0, 0);
+            accm[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(ct.w, vis, accm[3], 0, 0, 0);
+            if (DEPTH) acc[0] = __builtin_fmaf(g0.w, vis, acc[0]);
+          } else {
 #pragma unroll
-          for (int v = 0; v < DV; v++) {
-            const float4 c4 = scol[j * DV + v];
-            if (v * 4 < D) acc[v * 4] = __builtin_fmaf(c4.x, vis, acc[v * 4]);
-            if (v * 4 + 1 < D) acc[v * 4 + 1] = __builtin_fmaf(c4.y, vis, acc[v * 4 + 1]);
-            if (v * 4 + 2 < D) acc[v * 4 + 2] = __builtin_fmaf(c4.z, vis, acc[v * 4 + 2]);
-            if (v * 4 + 3 < D) acc[v * 4 + 3] = __builtin_fmaf(c4.w, vis, acc[v * 4 + 3]);
+            for (int v = 0; v < DV; v++) {
+              const float4 c4 = scol[j * DV + v];
+              if (v * 4 < D) acc[v * 4] = __builtin_fmaf(c4.x, vis, acc[v * 4]);
+              if (v * 4 + 1 < D) acc[v * 4 + 1] = __builtin_fmaf(c4.y, vis, acc[v * 4 + 1]);
+              if (v * 4 + 2 < D) acc[v * 4 + 2] = __builtin_fmaf(c4.z, vis, acc[v * 4 + 2]);
+              if (v * 4 + 3 < D) acc[v * 4 + 3] = __builtin_fmaf(c4.w, vis, acc[v * 4 + 3]);
+            }
+            if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
           }
-          if (DEPTH) acc[D] = __builtin_fmaf(g0.w, vis, acc[D]);
           T = valid ? nT : T;
           last16 = valid ? 16 * j : last16;
         }
@@ -378,8 +422,8 @@ __device__ __forceinline__ void raster_fwd_r_body(const RasterFwdArgs &a) {
     a.last_ids[pix] = last;
     float *o = a.out + pix * NCH;
 #pragma unroll
-    for (int c = 0; c < D; c++) o[c] = acc[c] + (a.background ? T * a.background[c] : 0.f);
-    if (DEPTH) o[D] = a.ed ? acc[D] / fmaxf(al, 1e-10f) : acc[D];
+    for (int c = 0; c < D; c++) o[c] = chan(c) + (a.background ? T * a.background[c] : 0.f);
+    if (DEPTH) o[D] = a.ed ? chan(D) / fmaxf(al, 1e-10f) : chan(D);
   }
 #ifdef D4GS_TRACE
   if (a.trace && tid == 0) {
@@ -396,8 +440,17 @@ template <int D, bool DEPTH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_raster_fwd_r8(const RasterFwdArgs a) {
   raster_fwd_r_body<D, DEPTH>(a);
 }
+// (D = 16, the matrix-pipe accumulators with the four-steps-per-read loop: asked for 6 waves per SIMD the kernel fits 76 VGPRs without
+// scratch; left alone the compiler takes 96 + 16 -> 4 waves)
+#ifndef D4GS_FWD_WIDE_WAVES
+#define D4GS_FWD_WIDE_WAVES 6
+#endif
 template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) k_raster_fwd_r(const RasterFwdArgs a) {
+__global__ void __launch_bounds__(256)
+#if D4GS_FWD_WIDE_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(D == 16 ? D4GS_FWD_WIDE_WAVES : 1, D == 16 ? D4GS_FWD_WIDE_WAVES : 10)))
+#endif
+k_raster_fwd_r(const RasterFwdArgs a) {
   raster_fwd_r_body<D, DEPTH>(a);
 }
 // the same two, also storing the segment-boundary states (few-tile launches; the kernels above stay as they are)
@@ -406,7 +459,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   raster_fwd_r_body<D, DEPTH, true>(a);
 }
 template <int D, bool DEPTH>
-__global__ void __launch_bounds__(256) k_raster_fwd_rs(const RasterFwdArgs a) {
+__global__ void __launch_bounds__(256)
+#if D4GS_FWD_WIDE_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(D == 16 ? D4GS_FWD_WIDE_WAVES : 1, D == 16 ? D4GS_FWD_WIDE_WAVES : 10)))
+#endif
+k_raster_fwd_rs(const RasterFwdArgs a) {
   raster_fwd_r_body<D, DEPTH, true>(a);
 }
 
