@@ -228,10 +228,14 @@ int d4gs_project_fwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
     d4gs_set_error("d4gs_project_fwd: N == 0");
     return D4GS_EINVAL;
   }
+  if (((uintptr_t)out->ctab & 15) != 0) {  // the colour-table rows are stored (and read back) 16 bytes at a time
+    d4gs_set_error("d4gs_project_fwd: D4gsProjOut.ctab must be 16-byte aligned");
+    return D4GS_EINVAL;
+  }
   return d4gs_project_fwd_impl(dims, in, out, (hipStream_t)stream);
 }
 
-static int check_binned(const char *who, const D4gsProjOut *proj, const D4gsIsect *isect) {
+static int check_binned(const char *who, const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect) {
   if (!proj || !isect || !proj->geom || !proj->ctab || !proj->depths || !proj->tile_rects || !proj->tiles_touched ||
       !proj->isect_offsets || !proj->tile_counts || !proj->tile_offsets || !proj->n_isect) {
     d4gs_set_error("%s: NULL projection buffer", who);
@@ -241,13 +245,19 @@ static int check_binned(const char *who, const D4gsProjOut *proj, const D4gsIsec
     d4gs_set_error("%s: NULL intersection list", who);
     return D4GS_EINVAL;
   }
+  // tiles_touched / isect_offsets / tile_counts were built from popcount(mask) by d4gs_project_fwd: walking whole rectangles
+  // against them (no masks) would run past every range they describe
+  if ((dims->flags & D4GS_EXACT_TILES) && !proj->tile_masks) {
+    d4gs_set_error("%s: D4GS_EXACT_TILES needs the D4gsProjOut.tile_masks d4gs_project_fwd wrote under the same flag", who);
+    return D4GS_EINVAL;
+  }
   return D4GS_OK;
 }
 
 int d4gs_bin_sort(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect *isect, void *stream) {
   int rc = check_dims(dims);
   if (rc) return rc;
-  if ((rc = check_binned("d4gs_bin_sort", proj, isect))) return rc;
+  if ((rc = check_binned("d4gs_bin_sort", dims, proj, isect))) return rc;
   return d4gs_bin_sort_impl(dims, proj, isect, (hipStream_t)stream);
 }
 
@@ -255,7 +265,7 @@ int d4gs_raster_fwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
                     void *stream) {
   int rc = check_dims(dims);
   if (rc) return rc;
-  if ((rc = check_binned("d4gs_raster_fwd", proj, isect))) return rc;
+  if ((rc = check_binned("d4gs_raster_fwd", dims, proj, isect))) return rc;
   if (!r || !r->render_colors || !r->render_alphas || !r->last_ids || !r->final_T) {
     d4gs_set_error("d4gs_raster_fwd: NULL output buffer");
     return D4GS_EINVAL;
@@ -267,7 +277,7 @@ int d4gs_raster_bwd(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIse
                     const D4gsRasterGrads *g, void *stream) {
   int rc = check_dims(dims);
   if (rc) return rc;
-  if ((rc = check_binned("d4gs_raster_bwd", proj, isect))) return rc;
+  if ((rc = check_binned("d4gs_raster_bwd", dims, proj, isect))) return rc;
   if (!r || !r->render_colors || !r->render_alphas || !r->last_ids || !r->final_T || !g || !g->v_render_colors ||
       !g->isect_grad || !g->isect_live || !g->v_means2d || !g->v_conics || !g->v_depths || !g->v_opac_act || !g->v_ctab) {
     d4gs_set_error("d4gs_raster_bwd: NULL forward state or gradient buffer");
@@ -299,6 +309,10 @@ int d4gs_project_bwd(const D4gsDims *dims, const D4gsProjIn *in, const D4gsProjO
   if (dims->G > 0 && (!in->motion_coefs || !in->rots || !in->transls || !in->times || !grads->v_motion_coefs ||
                       !grads->v_rots || !grads->v_transls)) {
     d4gs_set_error("d4gs_project_bwd: G>0 needs motion_coefs/rots/transls/times and their gradient buffers");
+    return D4GS_EINVAL;
+  }
+  if ((((uintptr_t)v_ctab | (uintptr_t)proj->ctab) & 15) != 0) {  // k_project_bwd reads the colour rows and their gradients as float4
+    d4gs_set_error("d4gs_project_bwd: v_ctab and D4gsProjOut.ctab must be 16-byte aligned");
     return D4GS_EINVAL;
   }
   return d4gs_project_bwd_impl(dims, in, proj, v_means2d, v_conics, v_depths, v_opac_act, v_ctab, grads,

@@ -162,6 +162,19 @@ def _size_key(dev, S, N, W, H):
     return (dev.index, S, W, H, (N >> shift) << shift)
 
 
+def _list_key(dev, cfg):
+    """Key of the list-size guess, the deferred records and the graph watch records of a render: the shape's size key plus the
+    RESOLVED exact-tiles flag.  Lists binned with D4GS_EXACT_TILES are 15-40 % shorter than the rectangles' (and may fall in a
+    smaller sort class), so a capacity measured under one flag says nothing about the other (a shared key let an
+    `auto` on -> off flip launch a deferred render at the stale, too small capacity).  The live fraction stays per shape."""
+    return _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height) + (bool(cfg.exact_tiles and cfg.exact_cull),)
+
+
+def _guess_drop(key):
+    with _SIZE_LOCK:
+        _SIZE_GUESS.pop(key, None)
+
+
 def _guess_get(key):
     with _SIZE_LOCK:
         g = _SIZE_GUESS.get(key)
@@ -190,6 +203,7 @@ LIVE_SPARSE_BELOW = 0.5
 def _live_put(key, live, sampled):
     if sampled <= 0:  # nothing sampled (empty lists): no evidence, keep what is known
         return
+    key = key[:5]  # (a list key: the shape's size key + the exact-tiles flag)
     with _SIZE_LOCK:
         _LIVE_FRAC[key] = live / sampled  # (a wide render's channel chunks count the same tiles once each: the ratio is unchanged)
         _LIVE_FRAC.move_to_end(key)
@@ -213,6 +227,7 @@ EXACT_TILES = os.environ.get("D4GS_EXACT_TILES", "auto")
 assert EXACT_TILES in ("0", "1", "auto"), f"D4GS_EXACT_TILES={EXACT_TILES!r}"
 EXACT_TILES_FROM = float(os.environ.get("D4GS_EXACT_TILES_FROM", "3.5"))  # intersections per (sub-sample, Gaussian) instance
 EXACT_TILES_MIN_LIVE = 0.5
+EXACT_TILES_LIVE_HYST = 0.1
 _XT_ON: dict = {}  # size key -> bool: the shape's current choice (hysteresis: the test itself shortens the lists it is decided from)
 
 
@@ -222,17 +237,26 @@ def resolve_lazy(cfg, dev):
         cfg.exact_tiles = EXACT_TILES == "1"
         if EXACT_TILES == "auto":  # the list capacity of the shape is 1.25 x the previous render's count (+ 4096)
             key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
-            guess = _guess_get(key)
-            per_inst = ((guess[0] - 4096) / 1.25 / (cfg.S * max(cfg.N, 1))) if guess else 0.0
             with _SIZE_LOCK:
-                on = _XT_ON.get(key, False)
+                was = _XT_ON.get(key, False)
                 live = _LIVE_FRAC.get(key)
-                on = per_inst >= (0.6 * EXACT_TILES_FROM if on else EXACT_TILES_FROM)  # on from 3.5 per instance, off again below 2.1
-                # ... but never for few-tile launches (their depth-segmented backward places its hand-offs by list length: shorter
-                # lists would move gradient bits between renders of one scene) and only where most list entries are alive - the
-                # composites must gain more than the test costs the projection (profiles/r05_ab_exact_tiles.txt: cfg3, 88 % live,
-                # -1.1 %; the training shape at 720p -1.8 %; cfg5, 20 % live: +-0; cfg2 with 2x / 4x splats, 16 / 4 % live: +1.5 / +12 %)
-                on = on and seg_state_elems(cfg) == 0 and (live is None or live >= EXACT_TILES_MIN_LIVE)
+            guess = _guess_get(key + (was,))  # the count measured under the flag the shape's last render ran with
+            per_inst = ((guess[0] - 4096) / 1.25 / (cfg.S * max(cfg.N, 1))) if guess else 0.0
+            # on from 3.5 per instance, off again below 2.1 (the test itself shortens the lists it is decided from)
+            on = per_inst >= (0.6 * EXACT_TILES_FROM if was else EXACT_TILES_FROM)
+            # ... but never for few-tile launches (their depth-segmented backward places its hand-offs by list length: shorter
+            # lists would move gradient bits between renders of one scene) and only where most list entries are alive - the
+            # composites must gain more than the test costs the projection (profiles/r05_ab_exact_tiles.txt: cfg3, 88 % live,
+            # -1.1 %; the training shape at 720p -1.8 %; cfg5, 20 % live: +-0; cfg2 with 2x / 4x splats, 16 / 4 % live: +1.5 / +12 %).
+            # Hysteresis on the live fraction too (on from 0.5, off below 0.4): a scene hovering at the line must not flap.
+            min_live = EXACT_TILES_MIN_LIVE - (EXACT_TILES_LIVE_HYST if was else 0.0)
+            on = on and seg_state_elems(cfg) == 0 and (live is None or live >= min_live)
+            if was and not on:
+                # on -> off: the rectangles' lists are longer by an unbounded factor (a thin diagonal splat), and whatever the
+                # off key still holds is from before the flag came on.  No guess = the next render of the shape COUNTS first
+                # (one host round trip; under stream capture: the explanatory error of _sized_launch) instead of launching blind.
+                _guess_drop(key + (False,))
+            with _SIZE_LOCK:
                 if len(_XT_ON) > 4 * _SIZE_GUESS_MAX:
                     _XT_ON.clear()
                 _XT_ON[key] = on
@@ -243,7 +267,7 @@ def resolve_lazy(cfg, dev):
             key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
             with _SIZE_LOCK:
                 f = _LIVE_FRAC.get(key)
-            guess = _guess_get(key)
+            guess = _guess_get(_list_key(dev, cfg))
             tw, th = cfg.tiles
             avg = (guess[0] / 1.25 / max(cfg.S * tw * th, 1)) if guess else 0.0
             cfg.lazy_sort = f is not None and f < LAZY_AUTO_LIVE and avg >= LAZY_AUTO_KEYS
@@ -251,7 +275,7 @@ def resolve_lazy(cfg, dev):
         key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
         with _SIZE_LOCK:
             f = _LIVE_FRAC.get(key)
-        guess = _guess_get(key)
+        guess = _guess_get(_list_key(dev, cfg))
         tw, th = cfg.tiles
         if f is not None and guess:  # about 2.5 x the entries a tile consumed on the previous render of the shape
             cfg.near_target = max(256, int(2.5 * f * guess[0] / 1.25 / max(cfg.S * tw * th, 1)))
@@ -544,7 +568,7 @@ def _sized_launch(cfg: "RenderCfg", dev, n_isect_dev, launch, count_needs_launch
     all return at once does the counting).  `fused_counts`: `launch` takes a third argument, the address of a pinned int64[4] its
     LAST kernel stores the counts to (D4gsFrameIO.counts_pinned: no d4gs_copy_counts launch behind it; 0 = none wanted).
     -> (capacity or exact count, max-tile value) the backward must use."""
-    key = _size_key(dev, cfg.S, cfg.N, cfg.width, cfg.height)
+    key = _list_key(dev, cfg)
     if cfg.deferred_size_check:
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing:

@@ -147,7 +147,8 @@ def train(steps=20, dev="cuda:0", W=512, H=288, verbose=True, control_every=0, f
         print(f"{1e3 * dt:.2f} ms / step  (3 render groups: 11 + 11 + 1 sub-samples, {model.num_gaussians} Gaussians, fwd + bwd + Adam)")
         if os.environ.get("D4GS_EXAMPLE_STATS"):  # what the engine measured per render shape: live-row fraction, list capacity
             for key, f in engine._LIVE_FRAC.items():
-                print("  shape", key, "live fraction %.3f" % f, "capacity", (engine._guess_get(key) or (None,))[0])
+                print("  shape", key, "live fraction %.3f" % f, "capacity (rectangles / exact tiles)",
+                      [(engine._guess_get(key + (xt,)) or (None,))[0] for xt in (False, True)])
         print(f"visible-instance count accumulated: {int(stats['vis_count'].sum())}")
     return losses, stats, dt
 

@@ -56,7 +56,10 @@ enum { /* D4gsDims.flags */
                            ellipse actually reaches (the corner tiles of a 2 x 2 ... 8 x 8 rectangle usually are not reached: 15 - 40 % shorter
                            lists at 720p).  The per-tile test runs in d4gs_project_fwd, the pairs of a wave's 64 instances spread over its
                            lanes, and leaves a 64-bit tile mask per instance (D4gsProjOut.tile_masks, required with the flag).  Same images
-                           and gradients bit for bit; tiles_touched / the lists get shorter.  Pays from ~3 tiles per instance on. */
+                           and gradients bit for bit; tiles_touched / the lists get shorter.  Pays from ~3 tiles per instance on.
+                           The flag must be THE SAME in the dims passed to d4gs_project_fwd, d4gs_bin_sort, d4gs_raster_fwd and
+                           d4gs_raster_bwd of one render (the counts and offsets are built from the masks; the binning walks them):
+                           with the flag and no tile_masks those calls return D4GS_EINVAL. */
   D4GS_EXACT_CULL = 4   /* bin a splat only into tiles that hold a pixel with alpha >= 1/255 (tight ellipse
                            sigma <= ln(255*opacity), intersected with gsplat's 3-sigma tile rectangle).  Pixels in
                            the dropped tiles would fail gsplat's alpha test anyway, so images and gradients are
@@ -105,7 +108,8 @@ typedef struct D4gsProjOut {
   float *conics;           /* [S,N,3] */
   int32_t *radii;          /* [S,N]  >0 <=> visible */
   float *opac_act;         /* [N]    activated opacity */
-  float *ctab;             /* [N,DP] activated colour table, DP = 4*ceil(D/4) */
+  float *ctab;             /* [N,DP] activated colour table, DP = 4*ceil(D/4); 16-byte aligned (rows are stored / read as 16-byte words:
+                              d4gs_project_fwd / d4gs_project_bwd return D4GS_EINVAL otherwise) */
   float *geom;             /* [S*N,8] packed raster record */
   int32_t *tile_rects;     /* [S*N,2] packed tile rectangle: x0 | x1<<16 , y0 | y1<<16 (min incl., max excl.) */
   int32_t *tiles_touched;  /* [S*N] */
@@ -181,7 +185,7 @@ typedef struct D4gsRasterGrads {
   float *v_conics;              /* [S,N,3] */
   float *v_depths;              /* [S,N]   (zeros when depth_mode == 0) */
   float *v_opac_act;            /* [N]     summed over S */
-  float *v_ctab;                /* [N,DP]  summed over S */
+  float *v_ctab;                /* [N,DP]  summed over S; 16-byte aligned (d4gs_project_bwd reads it as 16-byte words) */
   /* SURVEY 8f-1, fused: when stats_grad_norm_acc != NULL the gather epilogue also does the accumulation loop of
    * Trainer._prepare_control_step (flow3d/trainer.py:967-989) for this render - per visible instance (radii > 0), in
    * sub-sample order: grad_norm_acc[g] += |v_means2d * (W/2, H/2) * stats_batch_size * S|, vis_count[g] += 1, and, only

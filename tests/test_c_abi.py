@@ -78,6 +78,36 @@ def test_raster_bwd_rejects_misaligned_scratch_before_any_hip_call(lib):
         assert word in lib.d4gs_last_error(), lib.d4gs_last_error()
 
 
+def test_exact_tiles_and_alignment_contracts_are_checked_before_any_hip_call(lib):
+    """(a) D4GS_EXACT_TILES without D4gsProjOut.tile_masks in d4gs_bin_sort / d4gs_raster_fwd / d4gs_raster_bwd - the counts
+    and offsets were built from popcount(mask), rectangles walked against them would write out of bounds; (b) ctab / v_ctab are read
+    and written as 16-byte words by d4gs_project_fwd / d4gs_project_bwd.  Both are host-side D4GS_EINVAL (fake addresses)."""
+    from deblur4dgs_amd import _lib as L
+
+    lib.d4gs_last_error.restype = C.c_char_p
+    fake = 0x10000
+    d = L.Dims(N=10, G=0, K=0, T=0, S=1, D=3, width=16, height=16, flags=L.EXACT_CULL | L.EXACT_TILES)
+    pout = L.ProjOut(**{**{n: fake for n, _ in L.ProjOut._fields_}, "tile_masks": 0})
+    isect = L.Isect(n_isect=4, max_tile_count=0, keys=fake, gid_of_emit=fake, sorted_gid=fake, sorted_emit=fake)
+    ras = L.Raster(**{n: fake for n, _ in L.Raster._fields_})
+    rg = L.RasterGrads(v_render_colors=fake, isect_grad=fake, isect_live=fake, v_means2d=fake, v_conics=fake, v_depths=fake,
+                       v_opac_act=fake, v_ctab=fake)
+    for call in (lambda: lib.d4gs_bin_sort(C.byref(d), C.byref(pout), C.byref(isect), None),
+                 lambda: lib.d4gs_raster_fwd(C.byref(d), C.byref(pout), C.byref(isect), C.byref(ras), None),
+                 lambda: lib.d4gs_raster_bwd(C.byref(d), C.byref(pout), C.byref(isect), C.byref(ras), C.byref(rg), None)):
+        assert call() == -1 and b"tile_masks" in lib.d4gs_last_error(), lib.d4gs_last_error()
+    d = L.Dims(N=10, G=0, K=0, T=0, S=1, D=3, width=16, height=16)
+    pin = L.ProjIn(**{n: fake for n in ("means", "quats", "scales", "opacities", "colors", "viewmat", "Kmat")})
+    pout = L.ProjOut(**{**{n: fake for n, _ in L.ProjOut._fields_}, "ctab": fake + 4})
+    assert lib.d4gs_project_fwd(C.byref(d), C.byref(pin), C.byref(pout), None) == -1 and b"16-byte" in lib.d4gs_last_error()
+    lg = L.LeafGrads(**{n: fake for n in ("v_means", "v_quats", "v_scales", "v_opacities", "v_colors", "partials")})
+    vp = C.c_void_p
+    for pout, v_ctab in ((pout, fake), (L.ProjOut(**{n: fake for n, _ in L.ProjOut._fields_}), fake + 8)):
+        assert lib.d4gs_project_bwd(C.byref(d), C.byref(pin), C.byref(pout), vp(fake), vp(fake), vp(fake), vp(fake), vp(v_ctab),
+                                    C.byref(lg), None) == -1
+        assert b"16-byte" in lib.d4gs_last_error(), lib.d4gs_last_error()
+
+
 def test_struct_layouts_match_header():
     """ctypes mirrors must have exactly the fields of the C structs, in order."""
     from deblur4dgs_amd import _lib as L

@@ -102,3 +102,44 @@ def test_row_mode_follows_the_measured_live_fraction(monkeypatch):
     monkeypatch.setattr(engine, "BWD_ROWS", "sparse")
     assert engine.row_mode_for(cfg, dev) == L.ROWS_SPARSE
     engine._LIVE_FRAC.pop(key, None)
+
+
+def test_exact_tiles_auto_keeps_one_size_guess_per_flag_and_counts_again_after_on_to_off(monkeypatch):
+    """with D4GS_EXACT_TILES=auto the lists binned under the flag are 15-40 % shorter; the capacity measured with the
+    flag on must never size a render that runs with it off.  The guesses are keyed on the resolved flag, an on -> off flip
+    leaves NO guess for the off key (the next render counts first, also under deferred_size_check), and the live-fraction
+    condition has hysteresis."""
+    dev = torch.device("cuda", 0)
+    monkeypatch.setattr(engine, "EXACT_TILES", "auto")
+    monkeypatch.setattr(engine, "seg_state_elems", lambda cfg: 0)
+    S, N, W, H = 2, 1000, 640, 480
+    base = engine._size_key(dev, S, N, W, H)
+    mk = lambda: engine.RenderCfg(N=N, G=0, K=0, T=0, S=S, D=3, width=W, height=H)
+    cap = lambda per_inst: int(per_inst * S * N * 1.25) + 4096
+    for k in (base + (False,), base + (True,)):
+        engine._guess_drop(k)
+    engine._XT_ON.pop(base, None)
+    engine._LIVE_FRAC.pop(base, None)
+    try:
+        cfg = engine.resolve_lazy(mk(), dev)
+        assert cfg.exact_tiles is False and engine._list_key(dev, cfg) == base + (False,)  # nothing measured yet
+        engine._guess_put(base + (False,), (cap(4.0), 2048))  # rectangles: 4 intersections per instance -> on
+        cfg = engine.resolve_lazy(mk(), dev)
+        assert cfg.exact_tiles is True and engine._list_key(dev, cfg) == base + (True,)
+        assert engine._guess_get(engine._list_key(dev, cfg)) is None  # the render with the flag on does not inherit the off capacity
+        engine._guess_put(base + (True,), (cap(2.8), 512))  # what that render measured: shorter lists, a smaller sort class
+        engine._live_put(base, 45, 100)                      # 45 % live: below the 0.5 that turns it on, above the 0.4 that turns it off
+        assert engine.resolve_lazy(mk(), dev).exact_tiles is True
+        engine._live_put(base, 30, 100)                      # now it goes off ...
+        cfg = engine.resolve_lazy(mk(), dev)
+        assert cfg.exact_tiles is False
+        assert engine._guess_get(engine._list_key(dev, cfg)) is None  # ... and the stale off-key capacity is gone: count first
+        assert engine._guess_get(base + (True,)) == (cap(2.8), 512)    # a late deferred record of the on-render lands under ITS key
+        engine._live_put(base, 45, 100)
+        engine._guess_put(base + (False,), (cap(4.0), 2048))
+        assert engine.resolve_lazy(mk(), dev).exact_tiles is False     # 45 % does not turn it back on
+    finally:
+        for k in (base + (False,), base + (True,)):
+            engine._guess_drop(k)
+        engine._XT_ON.pop(base, None)
+        engine._LIVE_FRAC.pop(base, None)

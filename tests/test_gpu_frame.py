@@ -101,6 +101,60 @@ def test_exact_tiles_through_the_frame_paths(fused, monkeypatch):
             assert torch.equal(a.detach(), out[other][k].detach()), (k, other)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_exact_tiles_auto_turning_off_under_deferred_size_check_counts_again(fused, monkeypatch):
+    """ADVICE r5 (medium): `auto` had turned the exact-tiles test on, the shape's list capacity was measured with it (shorter lists);
+    then the live fraction drops and `auto` turns it off.  A deferred render used to launch at that stale capacity: its kernels
+    skipped the work (invalid frame) and a later poll raised.  Now the capacity is keyed on the flag and the flip leaves no
+    guess, so the render counts first: same bits as the plain render, nothing to complain about afterwards."""
+    from deblur4dgs_amd import engine
+
+    monkeypatch.setenv("D4GS_SEG", "0")
+    dev = torch.device("cuda:0")
+    N, G, K_, S, W, H = 9000, 6000, 4, 3, 512, 288
+    sc = make_scene(N, G, K_, S, W, H, seed=36)
+    sc["scales"] = sc["scales"] + 2.0
+    K = sc["K"].to(dev)
+    g = torch.Generator().manual_seed(9)
+    wb, wa = torch.randn(H, W, 4, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
+
+    def step(**kw):
+        L = _leaves(sc, dev)
+        r = _render(L, K, W, H, fused, **kw)
+        ((r["blended"] * wb).sum() + (r["acc"] * wa).sum()).backward()
+        return r, L
+
+    engine.check_deferred()
+    want, Lw = step(exact_tiles=False)
+    torch.cuda.synchronize()
+    n_off = want["state"].n_isect
+    monkeypatch.setattr(engine, "EXACT_TILES", "auto")
+    monkeypatch.setattr(engine, "EXACT_TILES_FROM", 1.5)
+    monkeypatch.setattr(engine, "EXACT_TILES_MIN_LIVE", 0.0)
+    monkeypatch.setattr(engine, "EXACT_TILES_LIVE_HYST", 0.0)
+    base = engine._size_key(dev, S, N, W, H)
+    engine._XT_ON.pop(base, None)
+    r1, _ = step(deferred_size_check=True)   # auto: on (the rectangles' count per instance), counts its own lists
+    r2, _ = step(deferred_size_check=True)   # launched at the capacity measured with the flag on
+    engine.check_deferred()
+    assert r1["state"].cfg.exact_tiles is True and r2["state"].cfg.exact_tiles is True
+    assert engine._guess_get(base + (True,))[0] < 1.25 * n_off + 4096  # the on-capacity: sized for the shorter lists
+    # whatever the off key holds dates from before the flag came on (here: a scene half the size) - it must not size the next render
+    engine._guess_put(base + (False,), (n_off // 2, 512))
+    monkeypatch.setattr(engine, "EXACT_TILES_MIN_LIVE", 2.0)  # "the live fraction dropped": auto turns the test off
+    r3, L3 = step(deferred_size_check=True)
+    engine.check_deferred()                   # used to raise: "... needed n intersections but its lists were sized for ..."
+    torch.cuda.synchronize()
+    assert r3["state"].cfg.exact_tiles is False and r3["state"].n_isect == n_off
+    assert torch.equal(r3["blended"], want["blended"]) and torch.equal(r3["renders"], want["renders"])
+    for k in NAMES:
+        assert torch.equal(L3[k].grad, Lw[k].grad), k
+    r4, L4 = step(deferred_size_check=True)   # and the next one runs deferred again, at the off-capacity
+    engine.check_deferred()
+    assert torch.equal(r4["blended"], want["blended"]) and torch.equal(L4["means"].grad, Lw["means"].grad)
+    engine._XT_ON.pop(base, None)
+
+
 def test_one_call_path_unblended_and_size_protocol():
     """blend=False (what exposure sharding renders), a cold size guess (the counting call), a warm one, and an overflowing
     deferred one - the protocol is the staged chain's."""
