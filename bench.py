@@ -59,6 +59,13 @@ FLOPS_PER_PAIR_FWD = 30.0
 FLOPS_INVALID_PAIR = 12.0  # what a pair that fails the alpha test needs at minimum: delta, sigma, exp, alpha, the test
 
 
+def flops_per_pair(bwd: bool, n_ch: int) -> float:
+    """SURVEY 8(d)'s ~30 / ~90 FP32 ops per (splat, pixel) are quoted at 4 composited channels (RGB + depth).  Per extra channel the
+    reference composite adds 2 forward (out += c * fac) and 8 backward (v_c = fac * v_out; v_alpha += (c * T - buffer * ra) * v_out;
+    buffer += c * fac): 22 + 2 C forward, 58 + 8 C backward - 30 / 90 at C = 4, 56 / 194 at the training shape's C = 17."""
+    return (58.0 + 8.0 * n_ch) if bwd else (22.0 + 2.0 * n_ch)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -859,9 +866,12 @@ def main():
             # geom 32 + colours 4*DP read, gradient row R*4 written; per pixel: v_out + v_alpha + alpha + last_id + T + out.
             DP = (channels + 3) // 4 * 4
             bytes_bwd = isect_replayed * (4 + 4 + 32 + 4 * DP + R * 4) + S_loc * H * W * (8.0 * (channels + 1) + 16.0)
+            default_workload = (channels == (16 if name.startswith("refdefault") else 3) and args.scale_mul == 1.0 and not args.lazy_sort
+                                and not args.spatial_order and args.share <= 1 and world == 1)  # the scene the committed counter passes ran on
             if dom.startswith("k_raster"):
-                flops = pairs_bwd * (FLOPS_PER_PAIR_BWD if "bwd" in dom else FLOPS_PER_PAIR_FWD)
-                tr = _traffic(name, dom) if channels == 3 and args.scale_mul == 1.0 else None
+                fpp = flops_per_pair("bwd" in dom, channels + 1)
+                flops = pairs_bwd * fpp
+                tr = _traffic(name, dom) if default_workload else None
                 # key order on purpose: what actually binds the kernel and the hardware fraction come BEFORE the contract's nominal fields
                 roof = {"kernel": dom, "bound_actual": "valu", "frac_hardware": None,
                         "bound": "mfma", "bound_note": "the kernel is bound by fp32 VALU issue; no MFMA is issued - the contract's "
@@ -873,27 +883,28 @@ def main():
                         "peak_measured_detail": {"v_pk_fma_f32": peaks["fp32_pk_fma_tflops"], "v_fma_f32": peaks["fp32_fma_tflops"]} if peaks else None,
                         "traffic": tr["total_1x"] if tr else None,
                         "traffic_detail": tr, "avg_launch_ms": t_k * 1e3, "pairs_per_launch": pairs_bwd,
-                        "note": "`frac` is the NOMINAL work-equivalent fraction SURVEY 8d defines: 90 flop x 256 pixels for every (tile, splat) "
+                        "flops_per_pair": fpp,
+                        "note": f"`frac` is the NOMINAL work-equivalent fraction SURVEY 8d defines: {fpp:.0f} flop x 256 pixels for every (tile, splat) "
                                 "pair the kernel replays, although the kernel skips most of those pixels by design (it can exceed the "
                                 "measured FMA ceiling).  `frac_hardware` (= hardware.frac_necessary) is the honest utilisation: flops the "
                                 "alpha-passing lanes need / peak; `hardware.valu_busy_frac` says how busy the pipe is doing it"}
                 # what the hardware does, from the committed PMC pass + the offline lane statistics of the same scene
                 cur = _load_json("profiles", "pmc_current.json") or {}
-                sq_doc = _load_json("profiles", f"{cur.get('round', 'r03')}_pmc_sq_cfg2.json")
-                sq_ok = _counters_current(sq_doc) and name == "cfg2" and channels == 3 and args.scale_mul == 1.0
+                sq_doc = _load_json("profiles", f"{cur.get('round', 'r03')}_pmc_sq_{name}.json")
+                sq_ok = _counters_current(sq_doc) and default_workload
                 sq = sq_doc.get(dom) if sq_ok else None
-                lanes = _load_json("profiles", f"{cur.get('round', 'r03')}_lane_stats_cfg2.json") if sq_ok else None
-                if not _counters_current(lanes):  # scripts/pair_stats.py of the same profiling round, same library
+                lanes = _load_json("profiles", f"{cur.get('round', 'r03')}_lane_stats_{name}.json") if sq_ok else None
+                if not _counters_current(lanes):  # scripts/lane_stats.py of the same profiling round, same library
                     lanes = None
-                if not sq_ok and name == "cfg2" and channels == 3:
+                if not sq_ok and default_workload:
                     roof["counters_note"] = ("profiles/ holds PMC counters of another build of libd4gs.so (sha256 mismatch): "
                                              "`traffic` / `hardware` / `frac_hardware` omitted rather than quoted stale; "
                                              "scripts/profile_round.sh re-measures them")
                 if sq:
                     clk_cycles = sq["GRBM_GUI_ACTIVE"] / N_XCD  # the counter is summed over the 8 XCDs
                     insts = sq["SQ_INSTS_VALU"]
-                    hw = {"source": f"profiles/{cur.get('round', 'r03')}_pmc_sq_cfg2.json (rocprofv3 --pmc, own pass, same libd4gs.so by "
-                                    f"sha256), profiles/{cur.get('round', 'r03')}_lane_stats_cfg2.json (scripts/pair_stats.py on the benched scene, same library)",
+                    hw = {"source": f"profiles/{cur.get('round', 'r03')}_pmc_sq_{name}.json (rocprofv3 --pmc, own pass, same libd4gs.so by "
+                                    f"sha256), profiles/{cur.get('round', 'r03')}_lane_stats_{name}.json (scripts/lane_stats.py on the benched scene, same library)",
                           "valu_wave_insts_per_launch": insts, "kernel_cycles": clk_cycles,
                           "cycles_per_valu_inst_per_simd": clk_cycles * N_SIMD / insts,
                           "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] / (clk_cycles * N_CU),
@@ -902,13 +913,13 @@ def main():
                         af = lanes["bwd_active_lane_fraction"]
                         vp = lanes["bwd_valid_pairs"] * (isect_replayed / max(lanes["n_isect"], 1))
                         replayed_lanes = lanes["bwd_quadrant_replays"] * 64.0 * (isect_replayed / max(lanes["n_isect"], 1))
-                        nec = vp * FLOPS_PER_PAIR_BWD + (replayed_lanes - vp) * FLOPS_INVALID_PAIR
+                        nec = vp * fpp + (replayed_lanes - vp) * FLOPS_INVALID_PAIR
                         hw.update(active_lane_fraction=af, replays_with_no_valid_lane=lanes["bwd_replays_with_no_valid_lane"],
                                   alpha_passing_pairs=lanes["bwd_valid_pairs"], nominal_pairs=lanes.get("bwd_nominal_pairs"),
                                   quadrant_replays=lanes["bwd_quadrant_replays"],
                                   necessary_flops_per_launch=nec, necessary_tflops=nec / t_k / 1e12,
                                   frac_necessary=nec / t_k / 1e12 / F32_PEAK_TFLOPS,
-                                  necessary_note="90 flop only for lanes that pass the alpha test, 12 for the other lanes "
+                                  necessary_note=f"{fpp:.0f} flop only for lanes that pass the alpha test, 12 for the other lanes "
                                                  "of a replayed (quadrant, splat) pair")
                         roof["frac_hardware"] = hw["frac_necessary"]
                     roof["hardware"] = hw

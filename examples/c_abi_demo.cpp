@@ -3,6 +3,10 @@
 // d4gs_forward / d4gs_backward (device pointers from hipMalloc, an explicit stream, one caller-provided workspace) and through
 // their CPU twins d4gs_forward_cpu / d4gs_backward_cpu (host pointers), and compares the two products: image, alpha and the
 // gradient of the means.  This is what a non-Python host of the reference's render path (flow3d/scene_model.py:313-397) binds.
+// Then the threading contract of the boundary (the reference renders from its trainer thread and from its viewer thread,
+// flow3d/trainer.py:204-207, flow3d/renderer.py:57-89): two host threads, each with its own stream, outputs and workspace, render the
+// same scene concurrently ten times - every frame and gradient must be BITWISE the single-threaded one - while one of them also makes a
+// failing call: its d4gs_last_error() names that failure, the other thread's stays empty (the string is thread-local).
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude examples/c_abi_demo.cpp -Ldeblur4dgs_amd -ld4gs -Wl,-rpath,$PWD/deblur4dgs_amd -o /tmp/c_abi_demo
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -10,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "d4gs.h"
@@ -58,6 +64,64 @@ static double frac_off(const std::vector<float> &a, const std::vector<float> &b,
   size_t n = 0;
   for (size_t i = 0; i < a.size(); i++) n += fabs((double)a[i] - (double)b[i]) > tol;
   return (double)n / (double)a.size();
+}
+
+// One host thread of the threading check: its own stream, outputs and workspace; the inputs are shared and read-only.
+struct ThreadRun {
+  std::vector<float> blend, v_means;
+  std::string err_after_bad_call, err_otherwise;
+  int rc = 0;
+};
+static int thread_body(const D4gsDims *dims, const D4gsProjIn *in_d, const float *bg_d, const float *d_wimg, const float *d_wacc, int64_t cap,
+                       int reps, bool provoke, ThreadRun *out) {
+  const int N = dims->N, S = dims->S, NCH = dims->D + 1;
+  const size_t P = (size_t)dims->height * dims->width;
+  hipStream_t stream;
+  HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  float *d_blend, *d_acc, *d_rend, *d_alpha, *d_m2d, *dv_means, *dv_quats, *dv_scales, *dv_opac, *dv_colors, *dv_view, *dv_m2d;
+  int32_t *d_radii;
+  int64_t *d_n;
+  HIP(hipMalloc(&d_blend, P * NCH * 4));
+  HIP(hipMalloc(&d_acc, P * 4));
+  HIP(hipMalloc(&d_rend, S * P * NCH * 4));
+  HIP(hipMalloc(&d_alpha, S * P * 4));
+  HIP(hipMalloc(&d_m2d, (size_t)S * N * 8));
+  HIP(hipMalloc(&d_radii, (size_t)S * N * 4));
+  HIP(hipMalloc(&d_n, 4 * sizeof(int64_t)));
+  HIP(hipMalloc(&dv_means, N * 12));
+  HIP(hipMalloc(&dv_quats, N * 16));
+  HIP(hipMalloc(&dv_scales, N * 12));
+  HIP(hipMalloc(&dv_opac, N * 4));
+  HIP(hipMalloc(&dv_colors, (size_t)N * dims->D * 4));
+  HIP(hipMalloc(&dv_view, 64));
+  HIP(hipMalloc(&dv_m2d, (size_t)S * N * 8));
+  const size_t ws_bytes = d4gs_frame_workspace_bytes(dims, cap);
+  void *ws;
+  HIP(hipMalloc(&ws, ws_bytes));
+  D4gsFrameIO io;
+  memset(&io, 0, sizeof io);
+  io.blended = d_blend, io.acc = d_acc, io.renders = d_rend, io.alphas = d_alpha, io.means2d = d_m2d, io.radii = d_radii, io.n_isect = d_n;
+  io.background = bg_d;
+  D4gsFrameGrads fg;
+  memset(&fg, 0, sizeof fg);
+  fg.v_blended = d_wimg, fg.v_acc = d_wacc, fg.v_means2d = dv_m2d;
+  D4gsLeafGrads lg;
+  memset(&lg, 0, sizeof lg);
+  lg.v_means = dv_means, lg.v_quats = dv_quats, lg.v_scales = dv_scales, lg.v_opacities = dv_opac, lg.v_colors = dv_colors, lg.v_viewmat = dv_view;
+  for (int r = 0; r < reps; r++) {
+    D4(d4gs_forward(dims, in_d, &io, ws, ws_bytes, cap, 0, stream));
+    if (provoke && r == reps / 2) {  // a failing call in the middle of this thread's frames: only THIS thread's string may change
+      if (d4gs_forward(nullptr, in_d, &io, ws, ws_bytes, cap, 0, stream) == D4GS_OK) return 5;
+      out->err_after_bad_call = d4gs_last_error();
+    }
+    D4(d4gs_backward(dims, in_d, &io, &fg, &lg, ws, ws_bytes, cap, 0, stream));
+  }
+  HIP(hipStreamSynchronize(stream));
+  if (!provoke) out->err_otherwise = d4gs_last_error();
+  out->blend.resize(P * NCH), out->v_means.resize((size_t)N * 3);
+  HIP(hipMemcpy(out->blend.data(), d_blend, out->blend.size() * 4, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(out->v_means.data(), dv_means, out->v_means.size() * 4, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int main() {
@@ -172,7 +236,24 @@ int main() {
          (long long)c_n[0], (long long)g_n[1]);
   printf("blended max|dev - cpu| / max = %.2e (%.1e of the elements beyond %.0e), acc %.2e\n", e_img, f_img, tol, e_acc);
   printf("v_means: %.1e of the elements beyond %.0e x max, v_colors: %.1e\n", f_means, tol, f_col);
-  const bool ok = g_n[0] == c_n[0] && f_img <= 2e-3 && f_means <= 2e-3 && f_col <= 2e-3 && e_acc < 2e-2;
+  bool ok = g_n[0] == c_n[0] && f_img <= 2e-3 && f_means <= 2e-3 && f_col <= 2e-3 && e_acc < 2e-2;
+
+  // ---- the threading contract: two host threads, two streams, concurrently; thread 1 also makes a failing call ----
+  const int T = 2, REPS = 10;
+  ThreadRun runs[T];
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++)
+    th.emplace_back([&, t]() { runs[t].rc = thread_body(&dims, &in_d, io_d.background, d_wimg, d_wacc, cap, REPS, t == 1, &runs[t]); });
+  for (auto &x : th) x.join();
+  bool same = true;
+  for (int t = 0; t < T; t++)
+    same = same && runs[t].rc == 0 && runs[t].blend.size() == g_blend.size() &&
+           memcmp(runs[t].blend.data(), g_blend.data(), g_blend.size() * 4) == 0 &&
+           memcmp(runs[t].v_means.data(), gv_means.data(), gv_means.size() * 4) == 0;
+  const bool tls = !runs[1].err_after_bad_call.empty() && runs[0].err_otherwise.empty();
+  printf("threads: %d x %d frames (forward + backward) on %d streams, bitwise the single-threaded frame: %s; error strings thread-local: %s (\"%s\" / \"%s\")\n",
+         T, REPS, T, same ? "yes" : "NO", tls ? "yes" : "NO", runs[1].err_after_bad_call.c_str(), runs[0].err_otherwise.c_str());
+  ok = ok && same && tls;
   printf(ok ? "OK\n" : "MISMATCH\n");
   return ok ? 0 : 1;
 }

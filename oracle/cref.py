@@ -110,3 +110,36 @@ def backward(ctx, v_out, v_alphas):
                       _p(v_means), _p(v_quats), _p(v_scales), _p(v_V))
     return dict(means=v_means, quats=v_quats, scales=v_scales, opac=v_op,
                 colors=v_col[:, :-1] if ctx["edd"] else v_col, viewmat=v_V, means2d=v_m2d, conics=v_con)
+
+
+def rasterization_torch(means, quats, scales, opacities, colors, viewmat, K, width, height, background=None,
+                        render_mode="RGB", near_plane=0.01, far_plane=1e10, eps2d=0.3, radius_clip=0.0):
+    """The scalar-C restatement behind ONE torch.autograd node, with oracle/raster.py `rasterization`'s signature and return
+    triple (fp64): lets oracle/scene.py - the exposure loop, channel assembly and blend of `SceneModel.render`
+    (flow3d/scene_model.py:162-487) - run at sizes the vectorised torch rasterizer does not finish in seconds (the
+    reference's own training shape: 140 k Gaussians, 11 sub-samples, 17 channels), with gradients flowing on through torch
+    autograd into the deformation and the camera generator.  tests/test_oracle_raster.py pins it to oracle/raster.py."""
+    import torch
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means, quats, scales, opacities, colors, viewmat):
+            n = lambda t: t.detach().double().cpu().numpy()
+            out, al, c = rasterization(n(means), n(quats), n(scales), n(opacities), n(colors), n(viewmat), n(K), width, height,
+                                       background=None if background is None else n(background), render_mode=render_mode,
+                                       near=near_plane, far=far_plane, eps2d=eps2d, radius_clip=radius_clip, dtype=np.float64)
+            ctx.c = c
+            seen.update(n_isect=c["n_isect"], radii=torch.from_numpy(c["radii"].copy()), means2d=torch.from_numpy(c["m2d"].copy()),
+                        depths=torch.from_numpy(c["dep"].copy()), tiles_per_gauss=torch.from_numpy(c["tiles_per_gauss"].copy()))
+            return torch.from_numpy(np.ascontiguousarray(out)), torch.from_numpy(np.ascontiguousarray(al))
+
+        @staticmethod
+        def backward(ctx, v_out, v_al):
+            g = backward(ctx.c, v_out.detach().double().numpy(), v_al.detach().double().numpy())
+            t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k]))
+            seen["v_means2d"] = t("means2d")  # (the densification statistics' input: flow3d/scene_model.py:456-461)
+            return t("means"), t("quats"), t("scales"), t("opac"), t("colors"), t("viewmat")
+
+    seen = {}  # what the forward saw, for the caller's `info` (plain tensors: not differentiable, as in oracle/raster.py)
+    rc, ra = _Fn.apply(means, quats, scales, opacities, colors, viewmat)
+    return rc, ra, seen

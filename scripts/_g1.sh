@@ -1,15 +1,13 @@
 set -x
 scripts/run.sh sha r6a
 date
-scripts/run.sh lanes r6a refdefault
-scripts/run.sh lanes r6a cfg3
+scripts/run.sh suite r6a
 date
-PMC_MORE=1 scripts/run.sh pmc r6a refdefault
+scripts/run.sh bench r6a
 date
-scripts/run.sh pmc r6a cfg3
-date
-scripts/run.sh pmc r6a cfg5
-date
-scripts/run.sh lanes r6a cfg5
-date
+for c in cfg2 refdefault cfg3 cfg5; do
+  scripts/run.sh lanes r6a $c
+  PMC_MORE=1 scripts/run.sh pmc r6a $c
+  date
+done
 ls gpurun_out | grep r6a

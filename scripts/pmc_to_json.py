@@ -45,6 +45,10 @@ doc["lib_sha256"] = lib_sha
 json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
 sq = parse(f"gpurun_out/pmc_{tag}_sq.txt")
 shutil.copy(f"gpurun_out/pmc_{tag}_sq.txt", f"profiles/{rnd}_pmc_sq_{cfg}.txt")
+if os.path.exists(f"gpurun_out/pmc_{tag}_sq2.txt"):  # PMC_MORE=1: a fourth pass (SALU / SMEM / VMEM / LDS-active / bank conflicts / MFMA)
+    for k, v in parse(f"gpurun_out/pmc_{tag}_sq2.txt").items():
+        sq.setdefault(k, {}).update(v)
+    shutil.copy(f"gpurun_out/pmc_{tag}_sq2.txt", f"profiles/{rnd}_pmc_sq2_{cfg}.txt")
 sq["lib_sha256"] = lib_sha
 json.dump(sq, open(f"profiles/{rnd}_pmc_sq_{cfg}.json", "w"), indent=1)
 json.dump({"lib_sha256": lib_sha, "round": rnd}, open("profiles/pmc_current.json", "w"), indent=1)

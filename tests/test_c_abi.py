@@ -108,6 +108,38 @@ def test_exact_tiles_and_alignment_contracts_are_checked_before_any_hip_call(lib
         assert b"16-byte" in lib.d4gs_last_error(), lib.d4gs_last_error()
 
 
+def test_last_error_is_thread_local(lib):
+    """SURVEY 8b's threading contract, host half (no GPU): d4gs_last_error() is per thread.  Two threads fail with DIFFERENT messages at
+    the same moment, a third never fails: each reads its own string (ctypes releases the GIL around the calls)."""
+    import threading
+
+    from deblur4dgs_amd import _lib as L
+
+    lib.d4gs_last_error.restype = C.c_char_p
+    bar = threading.Barrier(3)
+    seen = {}
+
+    def worker(name):
+        bar.wait()
+        for _ in range(200):
+            if name == "null_dims":
+                assert lib.d4gs_project_fwd(None, None, None, None) == -1
+            elif name == "motion_dims":
+                d = L.Dims(N=10, G=20, K=1, T=1, S=1, D=3, width=16, height=16)
+                assert lib.d4gs_project_fwd(C.byref(d), None, None, None) == -1
+            msg = lib.d4gs_last_error()
+            seen.setdefault(name, set()).add(msg)
+
+    th = [threading.Thread(target=worker, args=(n,)) for n in ("null_dims", "motion_dims", "quiet")]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert seen["quiet"] == {b""}
+    assert len(seen["null_dims"]) == 1 and b"NULL" in next(iter(seen["null_dims"]))
+    assert len(seen["motion_dims"]) == 1 and b"motion dims" in next(iter(seen["motion_dims"]))
+
+
 def test_struct_layouts_match_header():
     """ctypes mirrors must have exactly the fields of the C structs, in order."""
     from deblur4dgs_amd import _lib as L

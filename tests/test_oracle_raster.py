@@ -187,3 +187,40 @@ def test_k4_matrix_compose_equals_quaternion_path():
     lhs = deform.quat_wxyz_to_rotmat(torch.nn.functional.normalize(q, dim=-1))
     rhs = Rd @ deform.quat_wxyz_to_rotmat(qg)
     np.testing.assert_allclose(lhs.numpy(), rhs.numpy(), rtol=0, atol=1e-12)
+
+
+def test_k3_scene_oracle_on_the_scalar_c_rasterizer_equals_the_torch_one(monkeypatch):
+    """oracle/scene.py (the exposure loop, channel assembly and blend of SceneModel.render) with `cref.rasterization_torch` - the scalar-C
+    restatement behind one autograd node - in place of the vectorised torch rasterizer: same frame, same gradient of every leaf, the
+    bases, the camera deltas and the view matrix (1e-9).  This is what lets the full-size test of the reference's own training shape
+    (tests/test_gpu_refdefault_fullsize.py: 140 k Gaussians, 11 sub-samples, 3 + mask + 12 track channels + depth) use oracle/scene.py."""
+    from deblur4dgs_amd.synth import make_scene
+    from oracle import scene as oscene
+
+    N, G, K, S, W, H = 500, 300, 3, 3, 64, 48
+    sc = make_scene(N, G, K, S, W, H, seed=5, dtype=torch.float64, T=8)
+    sc["scales"] = sc["scales"] + 1.2
+    keys = ("means", "quats", "scales", "colors", "opacities")
+    tt = torch.tensor([1.0, 2.5, 4.0, 6.0], dtype=torch.float64)
+    res = {}
+    for which in ("torch", "c"):
+        if which == "c":
+            monkeypatch.setattr(oscene.raster, "rasterization", cref.rasterization_torch)
+        fg = {k: sc[k][:G].clone().requires_grad_() for k in keys}
+        fg["motion_coefs"] = sc["motion_coefs"].clone().requires_grad_()
+        bg = {k: sc[k][G:].clone().requires_grad_() for k in keys}
+        bases = {k: sc[k].clone().requires_grad_() for k in ("rots", "transls")}
+        RTs, w2c = sc["RTs"].clone().requires_grad_(), sc["viewmat"].clone().requires_grad_()
+        out = oscene.render_exposure(fg, bg, bases, sc["times"], RTs, w2c, sc["K"], (W, H), bg_color=1.0, return_depth=True,
+                                     return_mask=True, target_ts=tt)
+        assert out["exposure_imgs"].shape == (S, 1, H, W, 17)
+        g = torch.Generator().manual_seed(2)
+        loss = sum((out[k] * torch.randn(out[k].shape, generator=g, dtype=torch.float64)).sum()
+                   for k in ("img", "mask", "depth", "tracks_3d", "acc", "exposure_imgs"))
+        loss.backward()
+        res[which] = dict(**{k: out[k].detach() for k in ("img", "mask", "depth", "tracks_3d", "acc", "exposure_imgs")},
+                          **{f"fg.{k}": v.grad for k, v in fg.items()}, **{f"bg.{k}": v.grad for k, v in bg.items()},
+                          **{k: v.grad for k, v in bases.items()}, RTs=RTs.grad, w2c=w2c.grad[:3])
+    for k, a in res["torch"].items():
+        b = res["c"][k]
+        assert float((a - b).abs().max()) <= 1e-9 * max(1.0, float(a.abs().max())), k
