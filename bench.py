@@ -76,6 +76,8 @@ def parse():
                          "3-7 %% slow (list-size guesses, row mode and lazy-sort decisions settle within 3; the device then needs ~15 ms of "
                          "load to reach its sustained state - profiles/r04t_bench_ramp.txt), so with a short --warmup the mean of K timed "
                          "steps is the start-up ramp, not the frame time a training run sees")
+    ap.add_argument("--sustain", type=float, default=6.0,
+                    help="N = 1: seconds of the same step run after the timed region (reported as `sustained`, never as `value`); 0 = off")
     ap.add_argument("--config", default="cfg2", choices=list(CONFIGS))
     ap.add_argument("--shard", default="auto", choices=["auto", "exposure", "views", "mesh"],
                     help="N > 1: `exposure` = BASELINE config 4 (the S sub-samples of ONE frame over all ranks; strong scaling), `views` = one "
@@ -478,6 +480,8 @@ def main():
     from deblur4dgs_amd.parallel import ShardedExposure
 
     name = "tiny" if dry else args.config
+    if os.environ.get("D4GS_BENCH_S"):  # experiment hook (scripts/_g*.sh): the same scene with another number of exposure sub-samples
+        CONFIGS[name] = CONFIGS[name][:3] + (int(os.environ["D4GS_BENCH_S"]),) + CONFIGS[name][4:]
     N, G, K, S, W, H = CONFIGS[name]
     channels = args.channels or (16 if name.startswith("refdefault") else 3)
     if use_dist and primary_mesh[1] > S:
@@ -743,6 +747,19 @@ def main():
         kern, kern_all, n_break = {}, {}, 0
         if profile:
             kern = collect()  # the dominant kernels, measured live over the timed region
+        # sustained cross-check (N = 1, untimed for `value`): the SAME step function for --sustain seconds.  K = 20 steps are 25 ms of
+        # device time - too short for an outside monitor to see the GPU busy at all (the driver's 5-s samples read 0.0) and
+        # short enough to be a clock burst; the rate over several seconds is reported beside it.
+        if args.sustain > 0 and not dry and world == 1 and not args.share > 1:
+            n_s, t_s = 0, time.perf_counter()
+            while time.perf_counter() - t_s < args.sustain:
+                for _ in range(100):
+                    step()
+                sync()
+                n_s += 100
+            dt_s = time.perf_counter() - t_s
+            step_stats["sustained"] = {"steps": n_s, "seconds": dt_s, "ms_per_step": 1e3 * dt_s / n_s,
+                                       "note": f"the same step function run for >= {args.sustain:g} s right after the timed region (a host sync every 100 steps); not `value`"}
         if profile or (use_graph and prof_ok and not eager_first):
             n_break = min(steps, 10)  # untimed extra pass of EAGER steps with every kernel timed: the full per-kernel breakdown
             lib.d4gs_profile_enable(1)
@@ -839,6 +856,10 @@ def main():
         S_loc = st.cfg.S
         out["n_isect_per_step"] = n_isect if world == 1 else None
         out["config"]["pre_roll_steps"] = args.pre_roll
+        if "sustained" in step_stats:
+            sus = step_stats.pop("sustained")
+            sus["value"] = N / (sus["ms_per_step"] * 1e-3)
+            out["sustained"] = sus
         out["host_step_times"] = dict(step_stats, note="per-step host time between the returns of consecutive steps inside the timed region (diagnostic)")
         # (after every timed region: ~30 ms of full-rate FMA issue right in front of one cost it 0.2 % - 1.4052 against 1.4024 ms, four runs each)
         peaks = measured_peaks() if not args.no_peaks else None
@@ -874,8 +895,10 @@ def main():
                 tr = _traffic(name, dom) if default_workload else None
                 # key order on purpose: what actually binds the kernel and the hardware fraction come BEFORE the contract's nominal fields
                 roof = {"kernel": dom, "bound_actual": "valu", "frac_hardware": None,
-                        "bound": "mfma", "bound_note": "the kernel is bound by fp32 VALU issue; no MFMA is issued - the contract's "
-                        "field only admits hbm|mfma, and 157.3 TFLOP/s is both the fp32 vector and the fp32-input MFMA peak",
+                        "bound": "mfma", "bound_note": ("the kernel is bound by fp32 VALU issue; no MFMA is issued - the contract's "
+                        "field only admits hbm|mfma, and 157.3 TFLOP/s is both the fp32 vector and the fp32-input MFMA peak") if channels + 1 <= 5 else
+                        ("the 17-channel instance: fp32 VALU issue at 4 waves per SIMD (registers + 40 KB LDS); only the 16 colour channels' "
+                         "gradient rows go through the matrix pipe (v_mfma_f32_*: ~3 % of the issue slots) - the contract's field only admits hbm|mfma"),
                         "achieved": flops / t_k / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / t_k / 1e12 / F32_PEAK_TFLOPS,
                         "peak_measured": max(peaks["fp32_pk_fma_tflops"], peaks["fp32_fma_tflops"]) if peaks else None,
@@ -907,7 +930,16 @@ def main():
                                     f"sha256), profiles/{cur.get('round', 'r03')}_lane_stats_{name}.json (scripts/lane_stats.py on the benched scene, same library)",
                           "valu_wave_insts_per_launch": insts, "kernel_cycles": clk_cycles,
                           "cycles_per_valu_inst_per_simd": clk_cycles * N_SIMD / insts,
+                          # SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are summed over waves in units of 4 clocks (SQ_WAVE_CYCLES x 4 / (clocks x
+                          # 1024 SIMDs) reproduces the resident waves per SIMD): this is the average number of waves per SIMD that have a
+                          # VALU instruction in flight - ~1 = the vector pipe never idles; it exceeds 1 where issue and execution of
+                          # different waves overlap (cfg3 / cfg5: 1.17 - 1.19)
                           "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] / (clk_cycles * N_CU),
+                          "waves_resident_per_simd": sq["SQ_WAVE_CYCLES"] * 4.0 / (clk_cycles * N_SIMD) if "SQ_WAVE_CYCLES" in sq else None,
+                          "wave_time_valu_active_frac": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in sq else None,
+                          "wave_time_issue_stalled_frac": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in sq and "SQ_WAIT_INST_ANY" in sq else None,
+                          "lds_wave_insts_per_launch": sq.get("SQ_INSTS_LDS"), "mfma_wave_insts_per_launch": sq.get("SQ_INSTS_MFMA"),
+                          "salu_wave_insts_per_launch": sq.get("SQ_INSTS_SALU"),
                           "fp32_rate_if_every_inst_were_a_full_fma_tflops": insts * 64 * 2 / t_k / 1e12}
                     if lanes:
                         af = lanes["bwd_active_lane_fraction"]
@@ -946,6 +978,8 @@ def main():
                 "k_tile_sort": n_i * (8 + 4 + 4 + 4),
             }
             stream = []
+            if "k_tile_sort_w" in per:  # (lists of <= 512 keys sort in the one-wave register kernel: one pass over the same bytes)
+                per = dict(per, k_tile_sort=per.get("k_tile_sort", 0.0) + per["k_tile_sort_w"])
             for kname, b in alg.items():
                 if kname in per and per[kname] > 0:
                     tk = per[kname] * 1e-3

@@ -338,6 +338,15 @@ __device__ __forceinline__ void project_instance(const Cam &cam, const float *mw
 #ifndef D4GS_SEG_TILES_MAX
 #define D4GS_SEG_TILES_MAX 1280  // S * tiles above this: the plain kernels already fill the machine (>= 5 waves per SIMD)
 #endif
+// Round 6: renders of <= 4 colour channels keep their segments up to 2.5 rounds of the chip's 2048 workgroup slots.  The workgroup
+// trace of cfg2 (4608 tiles; profiles/r06_trace_bwd_cfg2.txt) shows full residency until the last workgroup is dispatched and then a
+// linear drain that lasts one workgroup LIFETIME (p50 233 us of a 620-us kernel) at ~77 % of the full rate; a quarter-length unit drains
+// in a quarter of the time.  Measured, plain vs segments (profiles/r06_ab_seg_threshold.txt): 3456 tiles 491 -> 437 us, 4608 619 -> 580
+// (forward +4: it writes the boundary states), 6912 880 -> 873 (+6), 9216 and up slower - the states cost in proportion to the tiles,
+// the drain does not.  The 17-channel kernels lose at every size above the rank shares (18 floats of state per pixel and boundary).
+#ifndef D4GS_SEG_TILES_MAX_NARROW
+#define D4GS_SEG_TILES_MAX_NARROW 5120
+#endif
 __host__ __device__ __forceinline__ int d4gs_seg_len(int len) {
   const int per = (len + D4GS_SEG_UNIT * D4GS_SEG_MAX - 1) / (D4GS_SEG_UNIT * D4GS_SEG_MAX);
   return D4GS_SEG_UNIT * (per > 1 ? per : 1);
@@ -599,6 +608,21 @@ __device__ __forceinline__ float4 d4gs_unpack_box(uint2 p) {
   return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
 }
 
+
+// Dynamic-LDS padding that caps a kernel's residency at `q` workgroups per CU (160 KB of LDS per CU; allocation granule taken as
+// 1280 B): the composites are issue-bound at 8 workgroups (= 8 waves per SIMD), and a launch whose workgroup count is not a multiple
+// of 256 x 8 ends in a partial round that runs at a fraction of the chip's issue rate (cfg2: 4608 workgroups = 2.25 rounds of 2048;
+// the last 512 take 0.43 of a full round's time).  Capping at q = 6 makes the same launch exactly 3 full rounds of 1536.
+inline int d4gs_lds_pad_for_wgs_per_cu(const void *kernel, int q) {
+  if (q <= 0 || q >= 8) return 0;
+  hipFuncAttributes at;
+  if (hipFuncGetAttributes(&at, kernel) != hipSuccess) return 0;
+  const int lds_cu = 160 * 1024, granule = 1280;
+  const int need = ((lds_cu / (q + 1) + 1 + granule - 1) / granule) * granule;  // > LDS / (q + 1): q + 1 workgroups no longer fit
+  if ((long)need * q > lds_cu) return 0;
+  const int pad = need - (int)at.sharedSizeBytes;
+  return pad > 0 ? pad : 0;
+}
 
 #define D4GS_LAUNCH(name, kernel, grid, block, lds, stream, ...)            \
   do {                                                                        \

@@ -841,8 +841,14 @@ int launch_bwd(RasterBwdArgs &a, GatherArgs &ga, int64_t n_isect, int row_mode, 
       if constexpr (D <= 5) D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_qs8<D, DEPTH>), dim3(sblocks), dim3(256), 0, stream, a);
       else D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_qs<D, DEPTH>), dim3(sblocks), dim3(256), 0, stream, a);
     } else if (n_isect > 0) {
-      if constexpr (D <= 5) D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q8<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
-      else D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+      static const int q_env = getenv("D4GS_BWD_Q") ? atoi(getenv("D4GS_BWD_Q")) : 0;  // A/B hook: workgroups per CU
+      if constexpr (D <= 5) {
+        const int pad = d4gs_lds_pad_for_wgs_per_cu((const void *)k_raster_bwd_q8<D, DEPTH>, q_env);
+        D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q8<D, DEPTH>), dim3(blocks), dim3(256), pad, stream, a);
+      } else {
+        const int pad = d4gs_lds_pad_for_wgs_per_cu((const void *)k_raster_bwd_q<D, DEPTH>, q_env);
+        D4GS_LAUNCH("k_raster_bwd_q", (k_raster_bwd_q<D, DEPTH>), dim3(blocks), dim3(256), pad, stream, a);
+      }
     }
   }
   int rc = d4gs_check_launch("k_raster_bwd");

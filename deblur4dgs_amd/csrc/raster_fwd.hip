@@ -488,8 +488,14 @@ int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
     else D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_rs<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
     return d4gs_check_launch("k_raster_fwd_r");
   }
-  if constexpr (D <= 4) D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r8<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
-  else D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r<D, DEPTH>), dim3(blocks), dim3(256), 0, stream, a);
+  static const int q_env = getenv("D4GS_FWD_Q") ? atoi(getenv("D4GS_FWD_Q")) : 0;  // A/B hook: workgroups per CU
+  if constexpr (D <= 4) {
+    const int pad = d4gs_lds_pad_for_wgs_per_cu((const void *)k_raster_fwd_r8<D, DEPTH>, q_env);
+    D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r8<D, DEPTH>), dim3(blocks), dim3(256), pad, stream, a);
+  } else {
+    const int pad = d4gs_lds_pad_for_wgs_per_cu((const void *)k_raster_fwd_r<D, DEPTH>, q_env);
+    D4GS_LAUNCH("k_raster_fwd_r", (k_raster_fwd_r<D, DEPTH>), dim3(blocks), dim3(256), pad, stream, a);
+  }
   return d4gs_check_launch("k_raster_fwd_r");
 }
 
@@ -499,7 +505,7 @@ int launch_fwd(const RasterFwdArgs &a, hipStream_t stream) {
 int64_t d4gs_seg_state_elems(const D4gsDims *d) {
   const int64_t tw = (d->width + D4GS_TILE - 1) / D4GS_TILE, th = (d->height + D4GS_TILE - 1) / D4GS_TILE;
   const int64_t n_tiles = (int64_t)d->S * tw * th;
-  if (n_tiles > D4GS_SEG_TILES_MAX) return 0;
+  if (n_tiles > (d->D <= 4 ? D4GS_SEG_TILES_MAX_NARROW : D4GS_SEG_TILES_MAX)) return 0;
   const int64_t nch = d->D + (d->depth_mode != D4GS_DEPTH_NONE ? 1 : 0);
   return n_tiles * D4GS_SEG_MAX * (1 + nch) * 256;
 }

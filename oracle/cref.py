@@ -130,7 +130,10 @@ def rasterization_torch(means, quats, scales, opacities, colors, viewmat, K, wid
                                        near=near_plane, far=far_plane, eps2d=eps2d, radius_clip=radius_clip, dtype=np.float64)
             ctx.c = c
             seen.update(n_isect=c["n_isect"], radii=torch.from_numpy(c["radii"].copy()), means2d=torch.from_numpy(c["m2d"].copy()),
-                        depths=torch.from_numpy(c["dep"].copy()), tiles_per_gauss=torch.from_numpy(c["tiles_per_gauss"].copy()))
+                        depths=torch.from_numpy(c["dep"].copy()), tiles_per_gauss=torch.from_numpy(c["tiles_per_gauss"].copy()),
+                        conics=torch.from_numpy(c["con"].copy()), flatten_ids=torch.from_numpy(c["flat"][: c["n_isect"]].copy()).long(),
+                        isect_offsets=torch.from_numpy(c["offs"].copy()).long(),
+                        inputs=tuple(torch.from_numpy(c[k].copy()) for k in ("means", "quats", "scales", "opac")))
             return torch.from_numpy(np.ascontiguousarray(out)), torch.from_numpy(np.ascontiguousarray(al))
 
         @staticmethod

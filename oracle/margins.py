@@ -31,9 +31,13 @@ _BIG = 1e9
 
 
 @torch.no_grad()
-def pixel_margins(means2d, conics, opacities, depths, flatten_ids, isect_offsets, width: int, height: int):
+def pixel_margins(means2d, conics, opacities, depths, flatten_ids, isect_offsets, width: int, height: int, pos_err_px: float | None = None):
     """fp64 tensors of the oracle's projection + its sorted tile lists -> per pixel [H,W]:
     m_alpha  min |ln(o e^-sigma) - ln(1/255)| over the splats of the tile's list the pixel can still composite (T_before > 1e-4),
+             LESS what the float32 projected centre alone moves ln(alpha) by: |d sigma / d centre|_1 x pos_err_px (default: 4 ulp of the
+             image size - means2d = fx x / z + cx is a float32 of magnitude <= max(W, H)).  A splat two pixels wide has conics of 2 - 3
+             px^-2: 1e-4 px of centre error is 5e-4 of alpha at its rim (measured: the one unexplained element of the reference's
+             training shape sat at a margin of 1.04e-4 on such a splat);
     m_T      min |ln(T_after) - ln(1e-4)| over the splats it does composite,
     m_clamp  min |ln(o e^-sigma) - ln(0.999)| over the same reachable splats (gradient kink only),
     m_order  min relative depth difference of two list-adjacent splats that BOTH pass the alpha test at the pixel."""
@@ -41,6 +45,8 @@ def pixel_margins(means2d, conics, opacities, depths, flatten_ids, isect_offsets
     out = [torch.full((height, width), _BIG, dtype=torch.float64) for _ in range(4)]
     offs = isect_offsets.tolist()
     ln_min, ln_max, ln_stop = math.log(raster.ALPHA_MIN), math.log(raster.ALPHA_MAX), math.log(raster.T_STOP)
+    if pos_err_px is None:
+        pos_err_px = 4.0 * 2.0 ** -24 * 2.0 ** math.ceil(math.log2(max(width, height)))
     for ty in range(tile_h):
         ys0, ys1 = ty * TILE, min((ty + 1) * TILE, height)
         for tx in range(tile_w):
@@ -64,7 +70,8 @@ def pixel_margins(means2d, conics, opacities, depths, flatten_ids, isect_offsets
             T_before = torch.cat([torch.ones_like(T_after[:, :1]), T_after[:, :-1]], dim=1)
             reach = T_before > raster.T_STOP * (1.0 - 1e-2)  # (with slack: a stop that moves by one splat moves what is reachable)
             big = torch.full_like(lna, _BIG)
-            d_alpha = torch.where(reach, (lna - ln_min).abs(), big)
+            grad1 = (cn[:, 0] * dx + cn[:, 1] * dy).abs() + (cn[:, 1] * dx + cn[:, 2] * dy).abs()
+            d_alpha = torch.where(reach, ((lna - ln_min).abs() - grad1 * pos_err_px).clamp(min=0.0), big)
             d_T = torch.where(reach & ~skip, (torch.log(T_after.clamp(min=1e-300)) - ln_stop).abs(), big)
             d_clamp = torch.where(reach, (lna - ln_max).abs(), big)
             z = depths[g]

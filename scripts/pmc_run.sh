@@ -4,7 +4,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p $R/gpurun_out
-cd /tmp && rocprofv3 --pmc "$@" --kernel-trace -d $R/gpurun_out/pmc_$tag -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-peaks $BENCH_ARGS > /dev/null 2>$R/gpurun_out/pmc_$tag.err
+cd /tmp && rocprofv3 --pmc "$@" --kernel-trace -d $R/gpurun_out/pmc_$tag -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-peaks --sustain 0 $BENCH_ARGS > /dev/null 2>$R/gpurun_out/pmc_$tag.err
 cd $R
 python - <<PY
 import sqlite3, glob, collections

@@ -52,7 +52,7 @@ if os.path.exists(f"gpurun_out/pmc_{tag}_sq2.txt"):  # PMC_MORE=1: a fourth pass
 sq["lib_sha256"] = lib_sha
 json.dump(sq, open(f"profiles/{rnd}_pmc_sq_{cfg}.json", "w"), indent=1)
 json.dump({"lib_sha256": lib_sha, "round": rnd}, open("profiles/pmc_current.json", "w"), indent=1)
-for lane in (f"gpurun_out/{tag}_lane_stats_{cfg}.json", f"gpurun_out/lane_stats_{cfg}.json"):  # scripts/lane_stats.py (stamped with the library hash itself)
+for lane in (f"gpurun_out/{tag}_lane_stats_{cfg}.json", f"gpurun_out/{tag.rsplit('_', 1)[0]}_lane_stats_{cfg}.json", f"gpurun_out/lane_stats_{cfg}.json"):  # scripts/lane_stats.py (stamped with the library hash itself)
     if os.path.exists(lane) and json.load(open(lane)).get("lib_sha256") == lib_sha:
         json.dump(json.load(open(lane)), open(f"profiles/{rnd}_lane_stats_{cfg}.json", "w"), indent=1)
         break

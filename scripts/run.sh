@@ -36,12 +36,12 @@ suite)
 bench)
   python bench.py "$@" 2>gpurun_out/${tag}_bench.err | tail -1 > gpurun_out/${tag}_bench.json; head -c 600 gpurun_out/${tag}_bench.json; echo ;;
 frames)
-  for c in "$@"; do python bench.py $c --no-cpu-baseline 2>/dev/null | line "$c"; done 2>&1 | tee -a gpurun_out/${tag}_frames.txt ;;
+  for c in "$@"; do python bench.py $c --no-cpu-baseline --sustain 0 2>/dev/null | line "$c"; done 2>&1 | tee -a gpurun_out/${tag}_frames.txt ;;
 prof)
   cfg=$1; shift
   args="--config $cfg"; [ $# -gt 0 ] && args="$*"
   steps=10; case "$args" in *cfg5*) steps=5;; esac
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_$cfg -o r -- python $R/bench.py $args --steps $steps --warmup 3 --no-cpu-baseline --no-profile --no-peaks > $R/gpurun_out/${tag}_bench_under_rocprof_$cfg.json 2>>$R/gpurun_out/${tag}_prof.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_$cfg -o r -- python $R/bench.py $args --steps $steps --warmup 3 --no-cpu-baseline --no-profile --no-peaks --sustain 0 > $R/gpurun_out/${tag}_bench_under_rocprof_$cfg.json 2>>$R/gpurun_out/${tag}_prof.err)
   db=$(find gpurun_out/${tag}_prof_$cfg -name "*.db" | head -1)
   [ -n "$db" ] && python scripts/rocpd_summary.py $db > gpurun_out/${tag}_kernel_stats_$cfg.csv
   csv=$(find gpurun_out/${tag}_prof_$cfg -name "*kernel_stats.csv" | head -1)

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the fp64 torch oracle is thousands of small CPU ops: on the GPU box's 256-thread host the default (one thread per core) spends
+    # its time in thread hand-offs (bench.py measured one cfg1 oracle frame at 205-831 s on 256 threads against ~3 s on 16)
+    import torch
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")

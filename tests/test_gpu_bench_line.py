@@ -41,3 +41,6 @@ def test_default_bench_line_carries_the_contract_fields():
     assert cpu["runs"]["cfg1/scalar_c"]["iters"] == 20 and cpu["runs"]["cfg1/torch"]["gaussians_per_s"] > 0 and cpu["runs"]["cfg2/scalar_c"]["iters"] == 3
     assert cpu["product_cpu_twin"]["config"] == "cfg1" and cpu["product_cpu_twin_cfg2"]["gaussians_per_s"] > 0 and cpu["product_cpu_twin_cfg2"]["cores"] == 1
     assert d["value"] > 100 * cpu["value"]  # (a reported baseline, not a target: only that both legs measured the same thing)
+    # the sustained cross-check (default 6 s of the same step right after the timed region; never `value`): within 15 % of the K-step rate
+    sus = d["sustained"]
+    assert sus["seconds"] >= 6.0 and sus["steps"] >= 1000 and abs(sus["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.15, sus
