@@ -17,7 +17,7 @@ def parse(path):
         if not m:
             continue
         k = m.group(1).strip().replace("void ", "").split("<")[0].split("(")[0]
-        k = re.sub(r"^(k_raster_(?:bwd_q|fwd_r))8$", r"\1", k)  # the 8-waves-per-SIMD entry points of the same bodies
+        k = re.sub(r"^(k_raster_(?:bwd_q|fwd_r))s?8?$", r"\1", k)  # the 8-waves-per-SIMD / depth-segment entry points of the same bodies
         out.setdefault(k, {})[m.group(2)] = round(float(m.group(3)), 1)
     return out
 

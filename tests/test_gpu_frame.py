@@ -74,9 +74,9 @@ def test_exact_tiles_through_the_frame_paths(fused, monkeypatch):
 
     monkeypatch.setenv("D4GS_SEG", "0")
     dev = torch.device("cuda:0")
-    N, G, K_, S, W, H = 9000, 6000, 4, 3, 512, 288  # (3 x 576 tiles: not a few-tile launch - `auto` never turns the test on there)
+    N, G, K_, S, W, H = 9000, 6000, 4, 3, 1024, 576  # (3 x 2304 tiles: beyond the launches that run depth segments - `auto` never turns the test on there)
     sc = make_scene(N, G, K_, S, W, H, seed=35)
-    sc["scales"] = sc["scales"] + 2.0  # exp(2) = 7.4 x: rectangles of 2 x 2 ... 4 x 4 tiles
+    sc["scales"] = sc["scales"] + 1.3  # exp(1.3) = 3.7 x at twice cfg2's focal length: rectangles of 2 x 2 ... 4 x 4 tiles
     K = sc["K"].to(dev)
     g = torch.Generator().manual_seed(7)
     wb, wa = torch.randn(H, W, 4, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
@@ -111,9 +111,9 @@ def test_exact_tiles_auto_turning_off_under_deferred_size_check_counts_again(fus
 
     monkeypatch.setenv("D4GS_SEG", "0")
     dev = torch.device("cuda:0")
-    N, G, K_, S, W, H = 9000, 6000, 4, 3, 512, 288
+    N, G, K_, S, W, H = 9000, 6000, 4, 3, 1024, 576  # (beyond the launches that run depth segments: `auto` is never on there)
     sc = make_scene(N, G, K_, S, W, H, seed=36)
-    sc["scales"] = sc["scales"] + 2.0
+    sc["scales"] = sc["scales"] + 1.3
     K = sc["K"].to(dev)
     g = torch.Generator().manual_seed(9)
     wb, wa = torch.randn(H, W, 4, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
