@@ -54,6 +54,7 @@ F32_PEAK_TFLOPS = 157.3  # fp32 vector peak == fp32-input dense MFMA peak (MI355
 N_CU, N_SIMD, N_XCD = 256, 1024, 8
 # ALGORITHMIC FP32 ops per (splat, pixel) of the reference composite (gsplat rasterize_to_pixels fwd / bwd at 4
 # channels), SURVEY.md section 8(d): ~30 forward, ~90 backward.  The HIP kernels execute fewer.
+CHECK_LAG = 4  # eager steps whose deferred list-size checks may still be pending while the host queues the next one
 FLOPS_PER_PAIR_BWD = 90.0
 FLOPS_PER_PAIR_FWD = 30.0
 FLOPS_INVALID_PAIR = 12.0  # what a pair that fails the alpha test needs at minimum: delta, sigma, exp, alpha, the test
@@ -615,7 +616,11 @@ def main():
             else:
                 last["st"] = sharder.step(leaves, d["K"], W, H, bg, wimg, wacc)
             if mode_flag["deferred"] and not dry:
-                engine.check_deferred()  # this step's list sizes, verified behind its launches (raises on overflow)
+                # every step's list sizes are verified (an overflow raises) - at most CHECK_LAG steps late, and all of them before the
+                # clock stops (round 6; rounds 4-5 waited for THIS step's forward here, which kept the host less than one step ahead of
+                # the device: two of three bench runs of one session caught a 4-ms host stall as +8 ... +12 % of a 20-step mean,
+                # profiles/r06_bench_host_stall.txt, at unchanged kernel times and an unchanged sustained rate)
+                engine.check_deferred(keep_last=CHECK_LAG)
 
         eager_step = step
         for _ in range(warmup):
@@ -737,6 +742,8 @@ def main():
             step()
             marks.append(time.perf_counter())  # (host time a step's calls returned: says WHERE a slow run lost its time)
         sync()
+        if not dry and mode_flag["deferred"]:
+            engine.check_deferred()  # the last CHECK_LAG steps' list sizes: everything has landed, nothing to wait for
         dt = time.perf_counter() - t0
         host_gaps = [b - a for a, b in zip([t0] + marks[:-1], marks)]
         step_stats["host_ms_median"] = 1e3 * sorted(host_gaps)[len(host_gaps) // 2]
@@ -843,7 +850,7 @@ def main():
             out["metric"] = f"DIAGNOSTIC rank-0 share of {name} at world size {args.share} (no collectives), Gaussians / t"
             out["config"]["workload"] += f"; ONLY sub-samples s % {args.share} == 0 rendered (--share)"
         out["config"]["size_check"] = ("host waits for every render's intersection counts" if args.sync_size_check else
-                                       "intersection counts verified once per step behind the launches (deferred)")
+                                       f"intersection counts of every step verified behind its launches (deferred): at most {CHECK_LAG} steps late, all of them before the clock stops")
         if res["graph_used"] or graph_note.get("fallback"):
             out["config"]["launch"] = graph_note.get("fallback") or (
                 "one HIP graph per step (render forward + backward" + (" + RCCL collectives" if use_dist else "")

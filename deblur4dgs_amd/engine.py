@@ -309,8 +309,9 @@ _DEFERRED: dict = {}  # size key -> [(pinned int64[4], event, capacity, max-tile
 _PINNED_FREE: list = []  # pinned int64[4] buffers whose deferred count has been consumed (guarded by _SIZE_LOCK)
 
 
-def _deferred_poll(key, block: bool = False):
-    """Look at the counts of the earlier deferred renders of this shape that have arrived (all of them when `block`).
+def _deferred_poll(key, block: bool = False, keep_last: int = 0):
+    """Look at the counts of the earlier deferred renders of this shape that have arrived (all of them when `block`; all but the
+    newest `keep_last` when `block` and keep_last > 0).
     Every record is verified - none is dropped when the host runs ahead of the device; an overflow raises after the
     whole batch has been read and the size guess updated.  -> (n, max_tile) of the newest record read | None."""
     with _SIZE_LOCK:
@@ -318,7 +319,7 @@ def _deferred_poll(key, block: bool = False):
         if not recs:
             return None
         ready = []
-        while recs and (block or recs[0][1].query()):  # stream order: an older copy lands before a newer one
+        while recs and ((block and len(recs) > keep_last) or recs[0][1].query()):  # stream order: an older copy lands before a newer one
             ready.append(recs.pop(0))
         if not recs:
             _DEFERRED.pop(key, None)
@@ -413,13 +414,15 @@ class GraphWatch:
                                "was INVALID (its kernels skipped the work).  Re-capture the step; the size guess is updated.")
 
 
-def check_deferred():
+def check_deferred(keep_last: int = 0):
     """Wait for and verify every outstanding deferred size check (call once per training step, e.g. where the loss is
-    read back anyway).  Raises RuntimeError if any render since the last call overflowed its intersection lists."""
+    read back anyway).  Raises RuntimeError if any render since the last call overflowed its intersection lists.
+    keep_last = n: do not wait for the newest n renders of each shape (they are verified by a later call) - the host then runs up to
+    n renders ahead of the device instead of waiting for this step's forward, so a host stall of a few milliseconds does not reach the GPU."""
     err = None
     for key in list(_DEFERRED):
         try:
-            _deferred_poll(key, block=True)
+            _deferred_poll(key, block=True, keep_last=keep_last)
         except RuntimeError as e:  # keep draining the other shapes: their records must not outlive this call
             err = err or e
     if err is not None:
