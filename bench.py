@@ -7,6 +7,11 @@ S exposure sub-samples -> camera delta -> projection -> tile binning + per-tile 
 exposure blend -> loss = <blended, Wimg> + <acc, Wacc> -> gradients to every leaf (means, quats, scales,
 opacities, colours, motion coefficients, bases, times, camera deltas, viewmat).  Inputs are resident in HBM
 before the timed region.  value = Gaussians / t_frame (whole job); `instances_per_s` = N*S / t_frame.
+The line also carries `roofline` (+ `roofline_hbm`, `roofline_streaming`) for the dominant kernel of WHATEVER `--config` was run - live
+launch durations from HIP events, counters from the hash-stamped files under profiles/ - the measured ceilings of the box, `cpu_baseline`
+(default config only), and `sustained`: the same step function run for `--sustain` seconds (default 6) right after the timed region,
+reported beside `value`, never as it.  Eager steps verify their intersection-list sizes at most CHECK_LAG steps late and all of them
+before the clock stops (`config.size_check`).
 
 Configs (`--config`): cfg1 / cfg2 (headline, default) / cfg3 / cfg5 = BASELINE.json's, `refdefault[720]` = the
 reference's own training shape (40 k dynamic + 100 k static Gaussians, 20 bases, 11 sub-samples, 17 channels:

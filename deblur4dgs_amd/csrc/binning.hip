@@ -572,6 +572,14 @@ int launch_emit(const EmitArgs &e, const D4gsDims *dims, int lz, hipStream_t str
     if (lz == 0) D4GS_EMIT(1, 0);
     else if (lz == 1) D4GS_EMIT(1, 1);
     else D4GS_EMIT(1, 2);
+  } else if (pt == 5) {
+    if (lz == 0) D4GS_EMIT(5, 0);
+    else if (lz == 1) D4GS_EMIT(5, 1);
+    else D4GS_EMIT(5, 2);
+  } else if (pt == 6) {
+    if (lz == 0) D4GS_EMIT(6, 0);
+    else if (lz == 1) D4GS_EMIT(6, 1);
+    else D4GS_EMIT(6, 2);
   } else {
     if (lz == 0) D4GS_EMIT(4, 0);
     else if (lz == 1) D4GS_EMIT(4, 1);
