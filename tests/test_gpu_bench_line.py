@@ -41,6 +41,8 @@ def test_default_bench_line_carries_the_contract_fields():
     assert cpu["runs"]["cfg1/scalar_c"]["iters"] == 20 and cpu["runs"]["cfg1/torch"]["gaussians_per_s"] > 0 and cpu["runs"]["cfg2/scalar_c"]["iters"] == 3
     assert cpu["product_cpu_twin"]["config"] == "cfg1" and cpu["product_cpu_twin_cfg2"]["gaussians_per_s"] > 0 and cpu["product_cpu_twin_cfg2"]["cores"] == 1
     assert d["value"] > 100 * cpu["value"]  # (a reported baseline, not a target: only that both legs measured the same thing)
-    # the sustained cross-check (default 6 s of the same step right after the timed region; never `value`): within 15 % of the K-step rate
+    # the sustained cross-check (default 6 s of the same step right after the timed region; never `value`).  This test times FOUR steps, so
+    # one host stall may double its mean: only that the two rates describe the same step (the real lines agree to 1 %: profiles/r06s_bench_*.json)
     sus = d["sustained"]
-    assert sus["seconds"] >= 6.0 and sus["steps"] >= 1000 and abs(sus["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.15, sus
+    assert sus["seconds"] >= 6.0 and sus["steps"] >= 1000 and 0.5 < sus["ms_per_step"] / d["ms_per_step"] < 1.5, sus
+    assert 0.9 < sus["ms_per_step"] < 2.0 and abs(sus["value"] - 300000 / (sus["ms_per_step"] * 1e-3)) <= 1e-6 * sus["value"]
