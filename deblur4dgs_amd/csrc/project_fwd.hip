@@ -65,17 +65,21 @@ k_project_fwd(const FwdArgs a) {
   const int g = blockIdx.x * D4GS_PROJ_BLOCK + tid;
   const Cam cam = load_cam(a.in.viewmat, a.in.Kmat, d.width, d.height);
   const bool dyn_block = (blockIdx.x * D4GS_PROJ_BLOCK) < G;
-  if (a.count_apart && a.out.tile_counts) {  // k_count_tiles (next in the stream) accumulates into a zeroed histogram: no memset node
+  // Round 6: gridDim.y sub-sample GROUPS.  A lane loops over S sub-samples, so the launch has only N / 64 waves - cfg2 4 688, the reference's
+  // training shape 2 188 for the chip's 8 192 wave slots (2.2 / 1.1 resident waves per SIMD: latency nobody hides).  Group y takes the
+  // iterations [y, y + 1) x ceil(S / gridDim.y) of the same loop; everything per Gaussian is recomputed per group and STORED by group 0 only.
+  const bool grp0 = blockIdx.y == 0;
+  if (a.count_apart && a.out.tile_counts && grp0) {  // k_count_tiles (next in the stream) accumulates into a zeroed histogram: no memset node
     const int n2 = 2 * S * a.tw * a.th;
     for (int z = g; z < n2; z += gridDim.x * D4GS_PROJ_BLOCK) a.out.tile_counts[z] = 0;
   }
-  if ((d.flags & D4GS_LAZY_SORT) && a.out.lazy_ws) {  // the lazy-sort counters start from zero as well
+  if ((d.flags & D4GS_LAZY_SORT) && a.out.lazy_ws && grp0) {  // the lazy-sort counters start from zero as well
     const int64_t nl = d4gs_lazy_ws_elems(S, a.tw * a.th);
     for (int64_t z = g; z < nl; z += (int64_t)gridDim.x * D4GS_PROJ_BLOCK) a.out.lazy_ws[z] = 0;
   }
   typedef const __attribute__((address_space(4))) float *cfloat_p;
   if (dyn_block && !TAB) preblend_bases(a, Bs);
-  if (blockIdx.x == 0 && dyn_block && !TAB && a.out.blend_bases) {  // the table k_project_bwd reads with scalar loads (include/d4gs.h)
+  if (blockIdx.x == 0 && grp0 && dyn_block && !TAB && a.out.blend_bases) {  // the table k_project_bwd reads with scalar loads (include/d4gs.h)
     __syncthreads();
     for (int idx = tid; idx < S * K * 16; idx += D4GS_PROJ_BLOCK) {
       const int j = idx & 15, sk = idx >> 4;
@@ -100,8 +104,8 @@ k_project_fwd(const FwdArgs a) {
     }
     opac = a.in.opacities[g];
     if (raw) opac = 1.f / (1.f + expf(-opac));
-    a.out.opac_act[g] = opac;
-    const int D = d.D, DP = (D + 3) & ~3;
+    if (grp0) a.out.opac_act[g] = opac;
+    const int D = grp0 ? d.D : 0, DP = (D + 3) & ~3;  // (the colour table row: group 0)
     // the colour table row: the channels that may need the sigmoid one by one (as before: the exp expansion stays single), the rest
     // 16 bytes at a time - a dword per channel and lane is DP stores of 64 scattered 4-byte pieces per wave: with 16 channels
     // k_project_fwd took 110 us against 64 with 3 (round 5)
@@ -151,7 +155,9 @@ k_project_fwd(const FwdArgs a) {
   __shared__ int xt_pre[XT ? D4GS_PROJ_BLOCK : 1];        // exclusive prefix of the wave's candidate (instance, tile) pairs
   __shared__ float4 xt_rec[XT ? D4GS_PROJ_BLOCK : 1][2];  // per instance: centre, conic, tau, packed rectangle origin / width
   __shared__ uint32_t xt_mask[XT ? D4GS_PROJ_BLOCK : 1][2];
-  for (int it = 0; it < S; it++) {
+  const int per_grp = (S + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int it_end = min(S, ((int)blockIdx.y + 1) * per_grp);
+  for (int it = (int)blockIdx.y * per_grp; it < it_end; it++) {
     if constexpr (!XT) {  // (the plain instantiation keeps its round-4 control flow - and its 64 VGPRs: idle lanes leave at once)
       if (!active) continue;
     }
@@ -842,9 +848,16 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
     const bool xt = dims->flags & D4GS_EXACT_TILES;
     const void *fn = xt ? (a.use_table ? (const void *)k_project_fwd<true, true> : (const void *)k_project_fwd<true, false>)
                         : (a.use_table ? (const void *)k_project_fwd<false, true> : (const void *)k_project_fwd<false, false>);
+    // sub-sample groups (the kernel's header comment): as many as keep the launch within ONE round of the chip's 2 048 four-wave slots
+    static const int sg_env = getenv("D4GS_PROJ_SG") ? atoi(getenv("D4GS_PROJ_SG")) : 0;  // A/B hook
+    // (measured, profiles/r06_ab_proj_groups.txt: the training shape - 547 blocks - 57.7 -> 44.1 us with 3 groups; cfg2 - 1 172 blocks - 65.3 -> 62.3
+    // with 2, 71 with 4; cfg5 - 3 907 blocks, two rounds already - slower with 2)
+    int sg = sg_env > 0 ? sg_env : 2048 / (blocks > 0 ? blocks : 1);
+    if (sg_env <= 0 && sg < 2 && blocks < 1536) sg = 2;
+    sg = sg < 1 ? 1 : (sg > dims->S ? dims->S : sg);
     ProfScope _ps("k_project_fwd", stream);
     void *kargs[] = {(void *)&a};
-    (void)hipLaunchKernel(fn, dim3(blocks), dim3(D4GS_PROJ_BLOCK), kargs, lds, stream);
+    (void)hipLaunchKernel(fn, dim3(blocks, sg), dim3(D4GS_PROJ_BLOCK), kargs, lds, stream);
   }
   int rc = d4gs_check_launch("k_project_fwd");
   if (rc) return rc;
