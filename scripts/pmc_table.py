@@ -8,6 +8,8 @@ cfgs = sys.argv[2:] or ["cfg2", "refdefault", "cfg3", "cfg5"]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda *a: os.path.join(ROOT, "profiles", *a)
 traffic = json.load(open(P("pmc_traffic.json")))
+if json.load(open(P(f"{rnd}_pmc_sq_{cfgs[0]}.json"))).get("lib_sha256") != traffic.get("lib_sha256"):
+    traffic = {"lib_sha256": json.load(open(P(f"{rnd}_pmc_sq_{cfgs[0]}.json"))).get("lib_sha256", "?")}  # (another build: no HBM column)
 out = [f"# Hardware counters per configuration ({rnd}; library sha256 {traffic.get('lib_sha256', '?')[:16]}...)", "",
        "`rocprofv3 --pmc` passes (own runs, kernel-trace only; `scripts/run.sh pmc`), averages per launch.  Clock = GRBM_GUI_ACTIVE / 8 XCDs at 2.4 GHz.",
        "SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_INST_ANY are summed over waves in units of 4 clocks (SQ_WAVE_CYCLES x 4 / (clocks x 1024 SIMDs) reproduces the",
