@@ -439,19 +439,49 @@ __device__ __forceinline__ void wave_sort_list(const SortArgs &a, int base, int 
     }
   }
 }
+// LONG (round 6): the workgroup also sorts those of its four lists that hold 513 ... 2 048 keys - all four waves through 16 KB of LDS, one
+// list after the other, exactly the network of k_tile_sort's first class.  A scene whose lists are mostly short (the reference's training
+// shape: p50 450 keys, a few hundred of 6 336 beyond 512; 720p) used to pay a whole launch of that class for the few: 19-21 / 11 us.
+template <bool LONG>
 __global__ void __launch_bounds__(256) k_tile_sort_w(const SortArgs a) {
-  if (over_capacity(a.n_dev, a.n_cap, a.max_hint)) return;
+  extern __shared__ __attribute__((aligned(16))) uint64_t wkeys[];  // LONG: 2 048 keys
+  if (over_capacity(a.n_dev, a.n_cap, a.max_hint)) return;  // (block-uniform)
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= a.n_lists) return;
-  int base = a.tile_offsets[t];
-  int n = a.tile_offsets[t + 1] - base;
-  if (a.pass && !lazy_range(a, t, base, n)) return;
-  if (n <= 0 || n > CHUNK) return;
-  if (n <= 64) wave_sort_list<1>(a, base, n, lane);
-  else if (n <= 128) wave_sort_list<2>(a, base, n, lane);
-  else if (n <= 256) wave_sort_list<4>(a, base, n, lane);
-  else wave_sort_list<8>(a, base, n, lane);
+  int base = 0, n = 0;
+  if (t < a.n_lists) {
+    base = a.tile_offsets[t];
+    n = a.tile_offsets[t + 1] - base;
+    if (a.pass && !lazy_range(a, t, base, n)) n = 0;
+  }
+  if (n > 0 && n <= CHUNK) {
+    if (n <= 64) wave_sort_list<1>(a, base, n, lane);
+    else if (n <= 128) wave_sort_list<2>(a, base, n, lane);
+    else if (n <= 256) wave_sort_list<4>(a, base, n, lane);
+    else wave_sort_list<8>(a, base, n, lane);
+  }
+  if constexpr (LONG) {
+    __shared__ int lb[4], ln[4];
+    if (lane == 0) lb[threadIdx.x >> 6] = base, ln[threadIdx.x >> 6] = (n > CHUNK && n <= 4 * CHUNK) ? n : 0;
+    __syncthreads();
+    for (int q = 0; q < 4; q++) {
+      const int nq = ln[q];  // (block-uniform)
+      if (nq == 0) continue;
+      const uint64_t *gk = a.keys + lb[q];
+      int P = CHUNK;
+      while (P < nq) P <<= 1;
+      const int fill = ((nq + CHUNK - 1) / CHUNK) * CHUNK;
+      for (int p = threadIdx.x; p < fill; p += blockDim.x) wkeys[p] = p < nq ? gk[p] : ~0ull;
+      __syncthreads();
+      bitonic_sort_lds(wkeys, P, nq);
+      for (int p = threadIdx.x; p < nq; p += blockDim.x) {
+        const uint32_t e = (uint32_t)wkeys[p];
+        a.sorted_emit[lb[q] + p] = (int32_t)e;
+        a.sorted_gid[lb[q] + p] = a.gid_of_emit[e];
+      }
+      __syncthreads();
+    }
+  }
 }
 
 __global__ void __launch_bounds__(1024) k_tile_sort(const SortArgs a) {
@@ -513,13 +543,21 @@ int launch_sorts(const D4gsDims *dims, const D4gsProjOut *proj, const D4gsIsect 
   // well above 512 keys (cfg2: 935): then that launch would find (almost) nothing to do and the few short lists ride in the first
   // LDS class's launch instead (wave 0 of their workgroup, same register sort): one launch less, 5 - 7 us per frame on cfg2.
   const bool merge_short = pass == 0 && longest > CHUNK && isect->n_isect >= (int64_t)768 * n_tiles;  // (capacity ~ 1.25 x the count)
+  // ... and the other way round (round 6): where the lists are mostly SHORT, the few of 513 ... 2 048 keys are sorted by the workgroup of
+  // k_tile_sort_w that owns them (all four waves, 16 KB of LDS) instead of a launch of the first LDS class for their sake.
+  static const bool no_long = getenv("D4GS_SORT_NO_MERGE_LONG") != nullptr;  // A/B hook
+  // Only whole-list passes whose lists average at most ~512 keys (capacity / tiles < 640): where many lists are long - the near / far
+  // passes of a lazy sort, cfg5: 609 -> 739 us - four of them queue up inside one workgroup.  Measured (profiles/r06_ab_sort_merge_long.txt):
+  // the reference's training shape 56.4 -> 46.8 us, cfg3 97.8 -> 87.7.
+  const bool merge_long = !merge_short && !no_long && longest > CHUNK && pass == 0 && isect->n_isect < (int64_t)640 * n_tiles;
   if (!merge_short) {
     SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
                0, CHUNK, proj->n_isect, isect->n_isect, isect->max_tile_count, n_tiles, lw.near, lw.flag, pass};
-    D4GS_LAUNCH("k_tile_sort_w", k_tile_sort_w, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, s);
+    if (merge_long) D4GS_LAUNCH("k_tile_sort_w", k_tile_sort_w<true>, dim3((n_tiles + 3) / 4), dim3(256), 4 * CHUNK * 8, stream, s);
+    else D4GS_LAUNCH("k_tile_sort_w", k_tile_sort_w<false>, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, s);
   }
   const int classes[6][3] = {{merge_short ? 0 : CHUNK, 2048, 256}, {2048, 4096, 512}, {4096, 8192, 1024}, {8192, 16384, 1024}, {16384, -1, 1024}};
-  for (int c = 0; c < 5; c++) {
+  for (int c = merge_long ? 1 : 0; c < 5; c++) {
     if (longest <= classes[c][0]) break;  // no list is that long
     SortArgs s{proj->tile_offsets, isect->keys, isect->gid_of_emit, isect->sorted_gid, isect->sorted_emit,
                classes[c][0], classes[c][1], proj->n_isect, isect->n_isect, isect->max_tile_count, n_tiles, lw.near, lw.flag, pass};
@@ -572,6 +610,14 @@ int launch_emit(const EmitArgs &e, const D4gsDims *dims, int lz, hipStream_t str
     if (lz == 0) D4GS_EMIT(1, 0);
     else if (lz == 1) D4GS_EMIT(1, 1);
     else D4GS_EMIT(1, 2);
+  } else if (pt == 2) {
+    if (lz == 0) D4GS_EMIT(2, 0);
+    else if (lz == 1) D4GS_EMIT(2, 1);
+    else D4GS_EMIT(2, 2);
+  } else if (pt == 3) {
+    if (lz == 0) D4GS_EMIT(3, 0);
+    else if (lz == 1) D4GS_EMIT(3, 1);
+    else D4GS_EMIT(3, 2);
   } else if (pt == 5) {
     if (lz == 0) D4GS_EMIT(5, 0);
     else if (lz == 1) D4GS_EMIT(5, 1);

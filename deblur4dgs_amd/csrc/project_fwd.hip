@@ -761,12 +761,15 @@ int d4gs_chunk_per_thread(const D4gsDims *d) {
   // Round 6: the 1024-lane blocks of k_count_tiles / k_emit fit two per CU = 512 at a time.  cfg2's 592 blocks (74 chunks x 8 sub-samples)
   // are one full round and one of 80 blocks that costs as much again; five or six instances per lane make the same launch ONE round
   // (472 blocks).  Only when it saves a round - beyond two rounds the longer dependent chain per lane costs more than the tail.
-  static const int pt_env = getenv("D4GS_CHUNK_PT") ? atoi(getenv("D4GS_CHUNK_PT")) : 0;  // A/B hook: 4 | 5 | 6
-  if (pt_env == 4 || pt_env == 5 || pt_env == 6) return pt_env;
+  static const int pt_env = getenv("D4GS_CHUNK_PT") ? atoi(getenv("D4GS_CHUNK_PT")) : 0;  // A/B hook: 2 ... 6
+  if (pt_env >= 2 && pt_env <= 6) return pt_env;
   const int64_t slots = 512;
-  if (blocks4 > slots && blocks4 <= 2 * slots && !(d->flags & D4GS_LAZY_SORT))  // (the lazy instantiations walk more per pair: 5 measured slower)
-    for (int pt = 5; pt <= 6; pt++)
-      if ((((int64_t)d->N + (int64_t)pt * COUNT_THREADS - 1) / ((int64_t)pt * COUNT_THREADS)) * d->S <= slots) return pt;
+  auto blocks_at = [&](int pt) { return (((int64_t)d->N + (int64_t)pt * COUNT_THREADS - 1) / ((int64_t)pt * COUNT_THREADS)) * d->S; };
+  if (d->flags & D4GS_LAZY_SORT) return 4;  // (the lazy instantiations walk more per pair: 5 measured slower)
+  // the FEWEST instances per lane that still make the launch one round: shorter dependent chains per lane, more blocks in flight
+  // (the reference's training shape: 4 -> 3 per lane, 385 -> 506 blocks)
+  for (int pt = 2; pt <= 6; pt++)
+    if (blocks_at(pt) <= slots) return pt;
   return 4;
 }
 
@@ -884,6 +887,10 @@ int d4gs_project_fwd_impl(const D4gsDims *dims, const D4gsProjIn *in, const D4gs
   } while (0)
     if (pt == 1 && lazy) D4GS_COUNT(1, true);
     else if (pt == 1) D4GS_COUNT(1, false);
+    else if (pt == 2 && lazy) D4GS_COUNT(2, true);
+    else if (pt == 2) D4GS_COUNT(2, false);
+    else if (pt == 3 && lazy) D4GS_COUNT(3, true);
+    else if (pt == 3) D4GS_COUNT(3, false);
     else if (pt == 5 && lazy) D4GS_COUNT(5, true);
     else if (pt == 5) D4GS_COUNT(5, false);
     else if (pt == 6 && lazy) D4GS_COUNT(6, true);
